@@ -1,0 +1,180 @@
+/* rthip.h — C ABI of librthip, the MI355X (gfx950) replacement for the CPU trace loop of
+ * Peanutt42/raytracer.
+ *
+ * The reference has no FFI or plugin interface; its seam is the Rust public API re-exported
+ * by src/lib.rs:1-19, and every caller owns the frame loop
+ * (raytracer_headless/src/main.rs:34-57, raytracer_runtime/src/main.rs:69-94,
+ * raytracer_terminal/src/main.rs:136-150).  This library replaces that loop, not the
+ * per-sample call: the scene and camera are handed over once, and one call renders
+ * `spp_count` samples of every pixel into an accumulation buffer that lives in HBM.
+ *
+ * Conventions: every function returns an int32 status (RTHIP_OK = 0), never unwinds or
+ * aborts across the ABI, takes plain pointers and sizes, and copies what it needs: the
+ * caller owns every host buffer it passes.  A context is bound to one GPU and must be used
+ * from one thread at a time.  Calls are synchronous unless noted.
+ */
+#ifndef RTHIP_H
+#define RTHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+	RTHIP_OK = 0,
+	RTHIP_ERR_INVALID = 1,  /* bad argument */
+	RTHIP_ERR_EMPTY = 2,    /* empty scene: BVH::new returns None (src/bvh.rs:51) */
+	RTHIP_ERR_STATE = 3,    /* scene or camera not set yet */
+	RTHIP_ERR_HIP = 4,      /* a HIP runtime call failed; see rthip_last_error */
+	RTHIP_ERR_LIMIT = 5     /* tree deeper than the traversal stack, image too large, ... */
+};
+
+enum { RTHIP_SPHERE = 0, RTHIP_CUBE = 1 };                           /* src/scene.rs:36-40 Object */
+enum { RTHIP_LAMBERTIAN = 0, RTHIP_METAL = 1, RTHIP_DIELECTRIC = 2 }; /* src/materials.rs:4-8 */
+enum { RTHIP_F32 = 0, RTHIP_F64 = 1 };
+enum { RTHIP_SKY_REFERENCE = 0, RTHIP_SKY_WALLPAPER = 1 };
+enum { RTHIP_MEGAKERNEL = 0, RTHIP_WAVEFRONT = 1 };
+
+/* One scene object, in f64 as the reference stores it (src/shapes/sphere.rs:4-9,
+ * src/shapes/cube.rs:4-9, src/materials.rs:4-8).  Objects are passed in insertion order;
+ * the index in that order is the object id (Scene::add_sphere / add_cube order,
+ * src/scene.rs:90-98; spheres then cubes for combine_spheres_and_cubes, src/scenes.rs:5-14).
+ * Negative radii and half extents are legal and keep the reference's meaning. */
+typedef struct rthip_object {
+	int32_t kind;      /* RTHIP_SPHERE | RTHIP_CUBE */
+	int32_t material;  /* RTHIP_LAMBERTIAN | RTHIP_METAL | RTHIP_DIELECTRIC */
+	double center[3];
+	double extent[3];  /* sphere: extent[0] = radius ; cube: half extents */
+	double albedo[3];  /* Lambertian, Metal */
+	double param;      /* Lambertian: emission ; Metal: fuzz ; Dielectric: ir */
+} rthip_object;
+
+/* Arguments of Camera::new (src/camera.rs:25-33).  The library derives the private fields
+ * of src/camera.rs:5-11 itself. */
+typedef struct rthip_camera_desc {
+	double origin[3];
+	double direction[3];
+	double fov;           /* degrees */
+	double focus_dist;
+	double defocus_angle; /* degrees; <= 0 disables the defocus offset (src/camera.rs:86) */
+	int32_t width, height;
+} rthip_camera_desc;
+
+/* One pass of the frame loop (raytracer_headless/src/main.rs:41-55): samples
+ * [spp_begin, spp_begin + spp_count) of every pixel this call owns. */
+typedef struct rthip_render_params {
+	uint32_t spp_begin, spp_count;
+	int32_t max_depth;  /* renderer.rs:34 */
+	uint32_t seed;      /* key of the counter-based random stream */
+	int32_t sky_mode;   /* RTHIP_SKY_* */
+	int32_t precision;  /* RTHIP_F32 (production) | RTHIP_F64 (reference arithmetic) */
+	int32_t variant;    /* RTHIP_MEGAKERNEL | RTHIP_WAVEFRONT */
+	/* Tile partition for multi-GPU runs: this call renders the 8x8 tiles whose row-major
+	 * index t satisfies t % part_count == part_index.  1 GPU: part_index 0, part_count 1. */
+	int32_t part_index, part_count;
+	int32_t reserved[3]; /* must be zero */
+} rthip_render_params;
+
+typedef struct rthip_stats {
+	uint64_t paths;         /* (pixel, sample) pairs rendered by the last render call */
+	uint64_t rays;          /* ray segments (one BVH::trace each) traced by it */
+	uint64_t box_tests;     /* filled by instrumented launches only, else 0 */
+	uint64_t sphere_tests;
+	uint64_t cube_tests;
+	double kernel_ms;       /* device time of the last render call's kernels (HIP events) */
+	int32_t n_nodes, n_leaves, n_prims, tree_depth; /* of the uploaded scene */
+	int32_t scene_in_lds;   /* 1 when the last render kept the scene in LDS */
+	int32_t reserved;
+} rthip_stats;
+
+typedef struct rthip_ctx rthip_ctx;
+
+/* Context on GPU `device` (ordinal as HIP sees it). */
+int32_t rthip_create(int32_t device, rthip_ctx** out);
+void rthip_destroy(rthip_ctx* ctx);
+/* Message for the last non-OK status of this context (or of rthip_create when ctx is NULL). */
+const char* rthip_last_error(const rthip_ctx* ctx);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
+
+/* Replaces BVH::new(scene) (src/bvh.rs:17-81): builds the reference-shaped median-split
+ * tree on the host, flattens it and uploads nodes, primitives and materials to HBM.
+ * n == 0 -> RTHIP_ERR_EMPTY. */
+int32_t rthip_scene_upload(rthip_ctx* ctx, const rthip_object* objects, int64_t n);
+/* Replaces Camera::new (src/camera.rs:25-69).  Changing the image size resets the
+ * accumulation buffer; changing only the pose does not (callers reset, as
+ * raytracer_runtime/src/main.rs:101-103,149 does). */
+int32_t rthip_camera_set(rthip_ctx* ctx, const rthip_camera_desc* cam);
+/* Host-only (no GPU needed): the derived fields Camera::new computes — origin, pixel00_loc,
+ * pixel_delta_x, pixel_delta_y, defocus_disk_x, defocus_disk_y (6 x 3 values) and
+ * defocus_angle (src/camera.rs:5-11,35-68). */
+int32_t rthip_camera_fields(const rthip_camera_desc* cam, double out[19]);
+
+/* Replaces the sample loop of raytracer_headless/src/main.rs:41-54 and the per-frame pass of
+ * raytracer_runtime/src/main.rs:69-86: adds sum_s sqrt(render(x, y, s)) to the accumulation
+ * buffer.  Results do not depend on how samples or tiles are split over calls or GPUs. */
+int32_t rthip_render_accumulate(rthip_ctx* ctx, const rthip_render_params* p);
+/* Asynchronous form: enqueues on the context's stream and returns.  Statistics are valid
+ * after rthip_synchronize. */
+int32_t rthip_render_accumulate_async(rthip_ctx* ctx, const rthip_render_params* p);
+int32_t rthip_synchronize(rthip_ctx* ctx);
+/* raytracer_runtime/src/main.rs:102-103 (accum_image cleared on a camera change). */
+int32_t rthip_reset_accumulation(rthip_ctx* ctx);
+
+/* The accumulation buffer: one uint64 per channel, 4 channels (r, g, b, unused) per pixel,
+ * counting units of 2^-36; pixels are stored tile-major (8x8 tiles, row-major inside a tile).
+ * Integer sums make merges across GPUs exact and order-independent.  The pointer is device
+ * memory owned by the context; n_words = tiles_x * tiles_y * 64 * 4. */
+int32_t rthip_accum_buffer(rthip_ctx* ctx, void** device_ptr, uint64_t* n_words);
+/* Use caller-owned device memory of n_words uint64 (e.g. a torch tensor, so that it can be
+ * handed to an RCCL collective) as the accumulation buffer; NULL returns to the own buffer. */
+int32_t rthip_set_accum_buffer(rthip_ctx* ctx, void* device_ptr, uint64_t n_words);
+
+/* Read back sum_s sqrt(sample) per channel, row-major [height][width][3] (the Vec<Vec3>
+ * `output` of raytracer_headless/src/main.rs:34 before the division of :55). */
+int32_t rthip_read_accum(rthip_ctx* ctx, double* rgb);
+/* raytracer_headless/src/main.rs:6-12,55: (accum / spp_total * 255.0) as u8, row-major RGB8. */
+int32_t rthip_read_rgb8(rthip_ctx* ctx, uint32_t spp_total, uint8_t* rgb);
+/* raytracer_runtime/src/main.rs:7-17,154-160: 0x00RRGGBB per pixel. */
+int32_t rthip_read_xrgb32(rthip_ctx* ctx, uint32_t spp_total, uint32_t* xrgb);
+
+/* Parity probe for BVH::trace (src/bvh.rs:130-142): one ray per pixel.  jitter = 0: from the
+ * camera origin through the pixel centre; jitter = 1: the ray Camera::get_ray produces for
+ * sample `sample` (src/camera.rs:83-92).  Outputs are host arrays, row-major; id = -1, t = 0
+ * on a miss.  t and normal are written as doubles in both precisions. */
+int32_t rthip_trace_primary(rthip_ctx* ctx, int32_t precision, int32_t jitter, uint32_t seed, uint32_t sample,
+                            int32_t* id, double* t, double* normal, uint8_t* front_face);
+/* Debug probe: linear radiance of every sample of render() (src/renderer.rs:29-40), host
+ * array [spp_count][height][width][3] of doubles, nothing accumulated. */
+int32_t rthip_render_samples(rthip_ctx* ctx, const rthip_render_params* p, double* samples);
+
+int32_t rthip_get_stats(rthip_ctx* ctx, rthip_stats* out);
+/* Host-only (no GPU needed): builds the tree of BVH::new (src/bvh.rs:17-81) and reports its
+ * shape: object ids leaf by leaf, left to right (reference order inside a leaf), the size of
+ * every leaf, the leaf count and the depth in inner-node levels.  ids holds n entries,
+ * leaf_sizes at most n; any output pointer may be NULL. */
+int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* ids, int32_t* leaf_sizes, int64_t* n_leaves,
+                             int32_t* depth);
+
+/* Seeded scene factories (no GPU needed).  Same distributions as the reference's factories,
+ * which draw from an OS-seeded generator and are therefore not reproducible themselves:
+ *   "default"   Scene::create_sample_scene          src/scene.rs:122-205
+ *   "simple"    create_simple_scene                 src/scenes.rs:17-75
+ *   "glass"     create_glass_scene                  src/scenes.rs:78-121
+ *   "metal"     create_10_metallic_scene            src/scenes.rs:124-170
+ *   "wallpaper" create_wallpaper_scene              src/scenes.rs:173-198
+ *   "sample"    scenes::create_sample_scene         src/scenes.rs:201-300 (many spheres and cubes)
+ *   "synthetic:N"  N random spheres and cubes (no counterpart in the reference)
+ * Writes at most `capacity` objects and returns the scene's object count in *n (call with
+ * capacity 0 to size the buffer). */
+int32_t rthip_scene_generate(const char* name, uint32_t seed, rthip_object* out, int64_t capacity, int64_t* n);
+/* get_camera_rotation (src/camera.rs:95-103). */
+void rthip_camera_rotation(double yaw_deg, double pitch_deg, double out[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTHIP_H */

@@ -1,0 +1,2 @@
+"""CPU oracle — test infrastructure only.  Imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; never by the product package."""

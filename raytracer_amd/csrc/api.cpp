@@ -1,0 +1,526 @@
+// api.cpp — the C ABI of librthip (include/rthip.h): context, uploads, launches, readback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rthip.h"
+#include "host.hpp"
+#include "launch.hpp"
+
+using namespace rthip;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct SceneBlob {  // one precision of the scene in HBM: [nodes | prims | mats]
+	char* dev = nullptr;
+	uint32_t prims_off = 0, mats_off = 0, gates_off = 0, bytes = 0;
+};
+inline uint32_t align_up(uint64_t v, uint32_t a) { return (uint32_t)((v + a - 1) / a * a); }
+}  // namespace
+
+struct rthip_ctx {
+	int device = 0;
+	int num_cu = 0;
+	hipStream_t own_stream = nullptr, stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	std::string err;
+
+	bool has_scene = false, has_camera = false;
+	SceneBlob blob32, blob64;
+	int tree_depth = 0, n_nodes = 0, n_leaves = 0, n_prims = 0, root_gate = -1;
+
+	CameraFields cam{};
+	int tiles_x = 0, tiles_y = 0;
+
+	unsigned long long* own_accum = nullptr;
+	uint64_t own_words = 0;
+	unsigned long long* accum = nullptr;  // active buffer (own or caller's)
+	uint64_t accum_words = 0;
+
+	char* d_control = nullptr;  // 64 bytes: queue counter at +0, 5 statistics words at +8
+	rthip_stats stats{};
+	bool launch_pending = false;
+	bool last_in_lds = false;
+};
+
+namespace {
+
+int32_t fail(rthip_ctx* c, int32_t code, const std::string& msg) {
+	if (c) c->err = msg; else g_create_error = msg;
+	return code;
+}
+#define HIP_TRY(ctx, expr)                                                                                     \
+	do {                                                                                                       \
+		hipError_t e_ = (expr);                                                                                \
+		if (e_ != hipSuccess) return fail((ctx), RTHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+	} while (0)
+
+template <typename Real> void fill_camera(const CameraFields& f, CameraT<Real>* c) {
+	for (int k = 0; k < 3; k++) {
+		c->origin[k] = (Real)f.origin[k]; c->pixel00[k] = (Real)f.pixel00[k];
+		c->delta_x[k] = (Real)f.delta_x[k]; c->delta_y[k] = (Real)f.delta_y[k];
+		c->disk_x[k] = (Real)f.disk_x[k]; c->disk_y[k] = (Real)f.disk_y[k];
+	}
+	c->defocus_angle = (Real)f.defocus_angle;
+}
+
+template <typename Real>
+int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const std::vector<Prim<Real>>& prims,
+                    const std::vector<Mat<Real>>& mats, const std::vector<Gate<Real>>& gates, SceneBlob* b) {
+	uint64_t nb = nodes.size() * sizeof(Node<Real>), pb = prims.size() * sizeof(Prim<Real>), mb = mats.size() * sizeof(Mat<Real>);
+	uint64_t gb = gates.size() * sizeof(Gate<Real>);
+	uint64_t prims_off = align_up(nb, 64), mats_off = align_up(prims_off + pb, 64), gates_off = align_up(mats_off + mb, 64);
+	uint64_t total = align_up(gates_off + gb, 64);
+	if (total > 0xFFFFFFF0ull) return fail(c, RTHIP_ERR_LIMIT, "scene larger than 4 GiB");
+	if (b->dev) { HIP_TRY(c, hipFree(b->dev)); b->dev = nullptr; }
+	std::vector<char> host((size_t)total, 0);
+	std::memcpy(host.data(), nodes.data(), (size_t)nb);
+	std::memcpy(host.data() + prims_off, prims.data(), (size_t)pb);
+	std::memcpy(host.data() + mats_off, mats.data(), (size_t)mb);
+	if (gb) std::memcpy(host.data() + gates_off, gates.data(), (size_t)gb);
+	HIP_TRY(c, hipMalloc(&b->dev, (size_t)total));
+	HIP_TRY(c, hipMemcpy(b->dev, host.data(), (size_t)total, hipMemcpyHostToDevice));
+	b->prims_off = (uint32_t)prims_off; b->mats_off = (uint32_t)mats_off; b->gates_off = (uint32_t)gates_off; b->bytes = (uint32_t)total;
+	return RTHIP_OK;
+}
+
+int env_int(const char* name, int dflt) {
+	const char* v = std::getenv(name);
+	return (v && *v) ? std::atoi(v) : dflt;
+}
+
+// Scenes up to this size are copied into LDS by every workgroup of the render kernel.
+constexpr uint32_t kLdsSceneLimit = 64 * 1024;
+
+struct Plan {
+	LaunchCfg cfg;
+	uint32_t chunk, n_chunks, n_items;
+	int32_t threshold;
+};
+
+int32_t validate(rthip_ctx* c, const rthip_render_params* p) {
+	if (!c) return RTHIP_ERR_INVALID;
+	if (!p) return fail(c, RTHIP_ERR_INVALID, "params is NULL");
+	if (!c->has_scene || !c->has_camera) return fail(c, RTHIP_ERR_STATE, "upload a scene and set a camera first");
+	if (p->precision != RTHIP_F32 && p->precision != RTHIP_F64) return fail(c, RTHIP_ERR_INVALID, "precision must be RTHIP_F32 or RTHIP_F64");
+	if (p->sky_mode != RTHIP_SKY_REFERENCE && p->sky_mode != RTHIP_SKY_WALLPAPER) return fail(c, RTHIP_ERR_INVALID, "unknown sky_mode");
+	if (p->variant != RTHIP_MEGAKERNEL) return fail(c, RTHIP_ERR_INVALID, "unknown variant");
+	if (p->part_count < 1 || p->part_index < 0 || p->part_index >= p->part_count) return fail(c, RTHIP_ERR_INVALID, "bad tile partition");
+	if (p->reserved[0] || p->reserved[1] || p->reserved[2]) return fail(c, RTHIP_ERR_INVALID, "reserved fields must be zero");
+	if ((uint64_t)p->spp_begin + p->spp_count > 0xFFFFFFFFull) return fail(c, RTHIP_ERR_INVALID, "sample range overflows");
+	return RTHIP_OK;
+}
+
+int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* plan) {
+	const bool f64 = p->precision == RTHIP_F64;
+	const SceneBlob& blob = f64 ? c->blob64 : c->blob32;
+	size_t stack_bytes = (size_t)c->tree_depth * kBlock * 4;
+	int lds_mode = env_int("RTHIP_SCENE_LDS", -1);
+	bool in_lds = lds_mode < 0 ? blob.bytes <= kLdsSceneLimit : (lds_mode != 0 && blob.bytes + stack_bytes <= 150 * 1024);
+	plan->cfg.scene_in_lds = in_lds;
+	plan->cfg.count = count;
+	plan->cfg.dyn_lds = stack_bytes + (in_lds ? blob.bytes : 0);
+	int bpc = 0;
+	HIP_TRY(c, f64 ? render_blocks_per_cu_f64(in_lds, plan->cfg.dyn_lds, &bpc) : render_blocks_per_cu_f32(in_lds, plan->cfg.dyn_lds, &bpc));
+	if (bpc < 1) return fail(c, RTHIP_ERR_LIMIT, "render kernel does not fit on a CU");
+	int cap = env_int("RTHIP_BLOCKS_PER_CU", 0);
+	if (cap > 0) bpc = std::min(bpc, cap);
+	uint64_t n_tiles = (uint64_t)c->tiles_x * c->tiles_y;
+	uint64_t my_tiles = n_tiles > (uint64_t)p->part_index ? (n_tiles - p->part_index + p->part_count - 1) / p->part_count : 0;
+	uint32_t chunk = (uint32_t)std::max(1, env_int("RTHIP_CHUNK", 8));
+	chunk = std::min<uint32_t>(chunk, std::max<uint32_t>(1u, p->spp_count));
+	uint32_t n_chunks = (p->spp_count + chunk - 1) / chunk;
+	uint64_t n_items = my_tiles * n_chunks;
+	if (n_items > 0xFFFFFF00ull) return fail(c, RTHIP_ERR_LIMIT, "too many work items in one call: lower spp_count");
+	plan->chunk = chunk; plan->n_chunks = n_chunks; plan->n_items = (uint32_t)n_items;
+	uint64_t want_blocks = (n_items + 3) / 4;
+	plan->cfg.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc * c->num_cu, want_blocks));
+	plan->threshold = env_int("RTHIP_TRAV_THRESHOLD", 24);
+	return RTHIP_OK;
+}
+
+template <typename Real>
+int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, unsigned long long* accum, Real* samples_out) {
+	Plan plan;
+	int32_t rc = make_plan(c, p, count, &plan);
+	if (rc != RTHIP_OK) return rc;
+	const SceneBlob& blob = std::is_same<Real, double>::value ? c->blob64 : c->blob32;
+	RenderArgs<Real> a;
+	std::memset(&a, 0, sizeof(a));
+	a.scene = blob.dev; a.prims_off = blob.prims_off; a.mats_off = blob.mats_off; a.gates_off = blob.gates_off; a.scene_bytes = blob.bytes;
+	a.root_gate = c->root_gate;
+	a.stack_entries = c->tree_depth;
+	fill_camera<Real>(c->cam, &a.cam);
+	a.width = c->cam.width; a.height = c->cam.height; a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y;
+	a.spp_begin = p->spp_begin; a.spp_count = p->spp_count; a.max_depth = p->max_depth; a.seed = p->seed;
+	a.sky_mode = p->sky_mode; a.part_index = p->part_index; a.part_count = p->part_count;
+	a.n_items = plan.n_items; a.chunk = plan.chunk; a.n_chunks = plan.n_chunks; a.trav_threshold = plan.threshold;
+	a.accum = accum; a.samples_out = samples_out;
+	a.queue = reinterpret_cast<uint32_t*>(c->d_control);
+	a.stats = reinterpret_cast<unsigned long long*>(c->d_control + 8);
+	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 64, c->stream));
+	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+	if (plan.n_items > 0 && p->spp_count > 0) HIP_TRY(c, launch_render(a, plan.cfg, c->stream));
+	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+	c->launch_pending = true;
+	c->last_in_lds = plan.cfg.scene_in_lds;
+	return RTHIP_OK;
+}
+
+int32_t collect_stats(rthip_ctx* c) {
+	if (!c->launch_pending) return RTHIP_OK;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	unsigned long long s[5];
+	HIP_TRY(c, hipMemcpy(s, c->d_control + 8, sizeof(s), hipMemcpyDeviceToHost));
+	float ms = 0.f;
+	HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	c->stats.paths = s[0]; c->stats.rays = s[1]; c->stats.box_tests = s[2]; c->stats.sphere_tests = s[3]; c->stats.cube_tests = s[4];
+	c->stats.kernel_ms = ms;
+	c->stats.scene_in_lds = c->last_in_lds ? 1 : 0;
+	c->launch_pending = false;
+	return RTHIP_OK;
+}
+
+int32_t ensure_accum(rthip_ctx* c) {
+	uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
+	if (c->accum && c->accum != c->own_accum) {
+		if (c->accum_words != words) return fail(c, RTHIP_ERR_STATE, "caller-owned accumulation buffer does not match the image size");
+		return RTHIP_OK;
+	}
+	if (c->own_words != words) {
+		if (c->own_accum) { HIP_TRY(c, hipFree(c->own_accum)); c->own_accum = nullptr; c->own_words = 0; }
+		HIP_TRY(c, hipMalloc(&c->own_accum, words * 8));
+		c->own_words = words;
+		HIP_TRY(c, hipMemsetAsync(c->own_accum, 0, words * 8, c->stream));
+	}
+	c->accum = c->own_accum; c->accum_words = words;
+	return RTHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rthip_create(int32_t device, rthip_ctx** out) {
+	if (!out) return fail(nullptr, RTHIP_ERR_INVALID, "out is NULL");
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n < 1) return fail(nullptr, RTHIP_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+	if (device < 0 || device >= n) return fail(nullptr, RTHIP_ERR_INVALID, "device ordinal out of range");
+	rthip_ctx* c = new rthip_ctx();
+	c->device = device;
+	auto bail = [&](const char* what, hipError_t err) {
+		std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+		rthip_destroy(c);
+		return fail(nullptr, RTHIP_ERR_HIP, msg);
+	};
+	if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+	hipDeviceProp_t prop;
+	if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+	c->num_cu = prop.multiProcessorCount;
+	if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+	c->stream = c->own_stream;
+	if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+	if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+	if ((e = hipMalloc(&c->d_control, 64)) != hipSuccess) return bail("hipMalloc", e);
+	*out = c;
+	return RTHIP_OK;
+}
+
+void rthip_destroy(rthip_ctx* c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->blob32.dev) (void)hipFree(c->blob32.dev);
+	if (c->blob64.dev) (void)hipFree(c->blob64.dev);
+	if (c->own_accum) (void)hipFree(c->own_accum);
+	if (c->d_control) (void)hipFree(c->d_control);
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+	delete c;
+}
+
+const char* rthip_last_error(const rthip_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int32_t rthip_set_stream(rthip_ctx* c, void* hip_stream) {
+	if (!c) return RTHIP_ERR_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	int32_t rc = collect_stats(c);
+	if (rc != RTHIP_OK) return rc;
+	c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+	return RTHIP_OK;
+}
+
+int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n) {
+	if (!c) return RTHIP_ERR_INVALID;
+	if (n < 0 || (n > 0 && !objects)) return fail(c, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
+	if (n == 0) return fail(c, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	FlatScene flat;
+	std::string err;
+	if (!build_flat_scene(objects, n, &flat, &err)) return fail(c, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+	c->has_scene = false;
+	int32_t rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32);
+	if (rc != RTHIP_OK) return rc;
+	rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
+	if (rc != RTHIP_OK) return rc;
+	c->root_gate = flat.root_gate;
+	c->tree_depth = flat.depth; c->n_nodes = (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)flat.prims32.size();
+	c->stats.n_nodes = c->n_nodes; c->stats.n_leaves = c->n_leaves; c->stats.n_prims = c->n_prims; c->stats.tree_depth = c->tree_depth;
+	c->has_scene = true;
+	return RTHIP_OK;
+}
+
+int32_t rthip_camera_set(rthip_ctx* c, const rthip_camera_desc* d) {
+	if (!c) return RTHIP_ERR_INVALID;
+	if (!d) return fail(c, RTHIP_ERR_INVALID, "camera is NULL");
+	if (d->width < 1 || d->height < 1 || (int64_t)d->width * d->height > (1ll << 28)) return fail(c, RTHIP_ERR_INVALID, "image size out of range");
+	if (!(d->focus_dist == d->focus_dist) || !(d->fov == d->fov)) return fail(c, RTHIP_ERR_INVALID, "camera has NaN fields");
+	HIP_TRY(c, hipSetDevice(c->device));
+	bool resized = !c->has_camera || d->width != c->cam.width || d->height != c->cam.height;
+	c->cam = camera_new(*d);
+	c->tiles_x = (d->width + kTile - 1) / kTile;
+	c->tiles_y = (d->height + kTile - 1) / kTile;
+	c->has_camera = true;
+	if (resized) {
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		if (c->accum && c->accum != c->own_accum) { c->accum = nullptr; c->accum_words = 0; }  // caller's buffer no longer fits
+		int32_t rc = ensure_accum(c);
+		if (rc != RTHIP_OK) return rc;
+		HIP_TRY(c, hipMemsetAsync(c->accum, 0, c->accum_words * 8, c->stream));
+	}
+	return RTHIP_OK;
+}
+
+int32_t rthip_camera_fields(const rthip_camera_desc* d, double out[19]) {
+	if (!d || !out) return fail(nullptr, RTHIP_ERR_INVALID, "camera or out is NULL");
+	if (d->width < 1 || d->height < 1) return fail(nullptr, RTHIP_ERR_INVALID, "image size out of range");
+	CameraFields f = camera_new(*d);
+	const double* src[6] = {f.origin, f.pixel00, f.delta_x, f.delta_y, f.disk_x, f.disk_y};
+	for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) out[3 * i + k] = src[i][k];
+	out[18] = f.defocus_angle;
+	return RTHIP_OK;
+}
+
+int32_t rthip_render_accumulate_async(rthip_ctx* c, const rthip_render_params* p) {
+	int32_t rc = validate(c, p);
+	if (rc != RTHIP_OK) return rc;
+	HIP_TRY(c, hipSetDevice(c->device));
+	if ((rc = collect_stats(c)) != RTHIP_OK) return rc;  // the control block is reused per launch
+	if ((rc = ensure_accum(c)) != RTHIP_OK) return rc;
+	bool count = env_int("RTHIP_COUNT", 0) != 0;
+	if (p->precision == RTHIP_F64) return enqueue_render<double>(c, p, count, c->accum, nullptr);
+	return enqueue_render<float>(c, p, count, c->accum, nullptr);
+}
+
+int32_t rthip_synchronize(rthip_ctx* c) {
+	if (!c) return RTHIP_ERR_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	int32_t rc = collect_stats(c);
+	if (rc != RTHIP_OK) return rc;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return RTHIP_OK;
+}
+
+int32_t rthip_render_accumulate(rthip_ctx* c, const rthip_render_params* p) {
+	int32_t rc = rthip_render_accumulate_async(c, p);
+	if (rc != RTHIP_OK) return rc;
+	return rthip_synchronize(c);
+}
+
+int32_t rthip_reset_accumulation(rthip_ctx* c) {
+	if (!c) return RTHIP_ERR_INVALID;
+	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+	HIP_TRY(c, hipSetDevice(c->device));
+	int32_t rc = ensure_accum(c);
+	if (rc != RTHIP_OK) return rc;
+	HIP_TRY(c, hipMemsetAsync(c->accum, 0, c->accum_words * 8, c->stream));
+	return RTHIP_OK;
+}
+
+int32_t rthip_accum_buffer(rthip_ctx* c, void** device_ptr, uint64_t* n_words) {
+	if (!c || !device_ptr || !n_words) return RTHIP_ERR_INVALID;
+	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+	HIP_TRY(c, hipSetDevice(c->device));
+	int32_t rc = ensure_accum(c);
+	if (rc != RTHIP_OK) return rc;
+	*device_ptr = c->accum; *n_words = c->accum_words;
+	return RTHIP_OK;
+}
+
+int32_t rthip_set_accum_buffer(rthip_ctx* c, void* device_ptr, uint64_t n_words) {
+	if (!c) return RTHIP_ERR_INVALID;
+	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if (!device_ptr) { c->accum = nullptr; c->accum_words = 0; return ensure_accum(c); }
+	uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
+	if (n_words != words) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must hold tiles_x*tiles_y*64*4 words");
+	if (reinterpret_cast<uintptr_t>(device_ptr) % 8) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must be 8-byte aligned");
+	c->accum = static_cast<unsigned long long*>(device_ptr); c->accum_words = words;
+	return RTHIP_OK;
+}
+
+int32_t rthip_read_accum(rthip_ctx* c, double* rgb) {
+	if (!c || !rgb) return RTHIP_ERR_INVALID;
+	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+	HIP_TRY(c, hipSetDevice(c->device));
+	int32_t rc = ensure_accum(c);
+	if (rc != RTHIP_OK) return rc;
+	size_t n = (size_t)c->cam.width * c->cam.height * 3;
+	double* d = nullptr;
+	HIP_TRY(c, hipMalloc(&d, n * sizeof(double)));
+	hipError_t e = launch_unpack(c->accum, d, c->cam.width, c->cam.height, c->tiles_x, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(rgb, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	(void)hipFree(d);
+	HIP_TRY(c, e);
+	return RTHIP_OK;
+}
+
+static int32_t read_quantized(rthip_ctx* c, uint32_t spp_total, void* out, int xrgb) {
+	if (!c || !out) return RTHIP_ERR_INVALID;
+	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+	if (spp_total == 0) return fail(c, RTHIP_ERR_INVALID, "spp_total must be positive");
+	HIP_TRY(c, hipSetDevice(c->device));
+	int32_t rc = ensure_accum(c);
+	if (rc != RTHIP_OK) return rc;
+	size_t bytes = (size_t)c->cam.width * c->cam.height * (xrgb ? 4 : 3);
+	void* d = nullptr;
+	HIP_TRY(c, hipMalloc(&d, bytes));
+	hipError_t e = launch_finalize(c->accum, d, c->cam.width, c->cam.height, c->tiles_x, spp_total, xrgb, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	(void)hipFree(d);
+	HIP_TRY(c, e);
+	return RTHIP_OK;
+}
+int32_t rthip_read_rgb8(rthip_ctx* c, uint32_t spp_total, uint8_t* rgb) { return read_quantized(c, spp_total, rgb, 0); }
+int32_t rthip_read_xrgb32(rthip_ctx* c, uint32_t spp_total, uint32_t* xrgb) { return read_quantized(c, spp_total, xrgb, 1); }
+
+int32_t rthip_trace_primary(rthip_ctx* c, int32_t precision, int32_t jitter, uint32_t seed, uint32_t sample, int32_t* id, double* t,
+                            double* normal, uint8_t* front_face) {
+	if (!c) return RTHIP_ERR_INVALID;
+	if (!id || !t || !normal || !front_face) return fail(c, RTHIP_ERR_INVALID, "output pointer is NULL");
+	if (!c->has_scene || !c->has_camera) return fail(c, RTHIP_ERR_STATE, "upload a scene and set a camera first");
+	if (precision != RTHIP_F32 && precision != RTHIP_F64) return fail(c, RTHIP_ERR_INVALID, "precision must be RTHIP_F32 or RTHIP_F64");
+	HIP_TRY(c, hipSetDevice(c->device));
+	size_t n = (size_t)c->cam.width * c->cam.height;
+	char* d = nullptr;
+	size_t off_t = align_up(n * 4, 64), off_n = off_t + align_up(n * 8, 64), off_f = off_n + align_up(n * 24, 64), total = off_f + align_up(n, 64);
+	HIP_TRY(c, hipMalloc(&d, total));
+	size_t lds = (size_t)c->tree_depth * kBlock * 4;
+	hipError_t e;
+	if (precision == RTHIP_F64) {
+		ProbeArgs<double> a;
+		std::memset(&a, 0, sizeof(a));
+		a.scene = c->blob64.dev; a.prims_off = c->blob64.prims_off; a.mats_off = c->blob64.mats_off; a.gates_off = c->blob64.gates_off;
+		a.scene_bytes = c->blob64.bytes; a.root_gate = c->root_gate;
+		a.stack_entries = c->tree_depth; fill_camera<double>(c->cam, &a.cam);
+		a.width = c->cam.width; a.height = c->cam.height; a.seed = seed; a.sample = sample; a.jitter = jitter;
+		a.id = reinterpret_cast<int32_t*>(d); a.t = reinterpret_cast<double*>(d + off_t); a.normal = reinterpret_cast<double*>(d + off_n);
+		a.front = reinterpret_cast<uint8_t*>(d + off_f);
+		e = launch_probe(a, lds, c->stream);
+	} else {
+		ProbeArgs<float> a;
+		std::memset(&a, 0, sizeof(a));
+		a.scene = c->blob32.dev; a.prims_off = c->blob32.prims_off; a.mats_off = c->blob32.mats_off; a.gates_off = c->blob32.gates_off;
+		a.scene_bytes = c->blob32.bytes; a.root_gate = c->root_gate;
+		a.stack_entries = c->tree_depth; fill_camera<float>(c->cam, &a.cam);
+		a.width = c->cam.width; a.height = c->cam.height; a.seed = seed; a.sample = sample; a.jitter = jitter;
+		a.id = reinterpret_cast<int32_t*>(d); a.t = reinterpret_cast<double*>(d + off_t); a.normal = reinterpret_cast<double*>(d + off_n);
+		a.front = reinterpret_cast<uint8_t*>(d + off_f);
+		e = launch_probe(a, lds, c->stream);
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e == hipSuccess) e = hipMemcpy(id, d, n * 4, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(t, d + off_t, n * 8, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(normal, d + off_n, n * 24, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(front_face, d + off_f, n, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	HIP_TRY(c, e);
+	return RTHIP_OK;
+}
+
+int32_t rthip_render_samples(rthip_ctx* c, const rthip_render_params* p, double* samples) {
+	int32_t rc = validate(c, p);
+	if (rc != RTHIP_OK) return rc;
+	if (!samples) return fail(c, RTHIP_ERR_INVALID, "samples is NULL");
+	if (p->part_count != 1) return fail(c, RTHIP_ERR_INVALID, "the sample probe renders the whole image");
+	HIP_TRY(c, hipSetDevice(c->device));
+	if ((rc = collect_stats(c)) != RTHIP_OK) return rc;
+	size_t n = (size_t)c->cam.width * c->cam.height * 3 * p->spp_count;
+	if (n > (1ull << 31)) return fail(c, RTHIP_ERR_LIMIT, "sample probe is for small images");
+	uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
+	size_t elem = p->precision == RTHIP_F64 ? 8 : 4;
+	char* d_samples = nullptr;
+	unsigned long long* d_scratch = nullptr;
+	HIP_TRY(c, hipMalloc(&d_samples, n * elem));
+	hipError_t e = hipMalloc(&d_scratch, words * 8);
+	if (e != hipSuccess) { (void)hipFree(d_samples); HIP_TRY(c, e); }
+	(void)hipMemsetAsync(d_samples, 0, n * elem, c->stream);
+	(void)hipMemsetAsync(d_scratch, 0, words * 8, c->stream);
+	bool count = env_int("RTHIP_COUNT", 0) != 0;
+	if (p->precision == RTHIP_F64) rc = enqueue_render<double>(c, p, count, d_scratch, reinterpret_cast<double*>(d_samples));
+	else rc = enqueue_render<float>(c, p, count, d_scratch, reinterpret_cast<float*>(d_samples));
+	if (rc == RTHIP_OK) rc = collect_stats(c);
+	if (rc == RTHIP_OK) {
+		if (p->precision == RTHIP_F64) {
+			e = hipMemcpy(samples, d_samples, n * 8, hipMemcpyDeviceToHost);
+		} else {
+			std::vector<float> tmp(n);
+			e = hipMemcpy(tmp.data(), d_samples, n * 4, hipMemcpyDeviceToHost);
+			for (size_t i = 0; i < n; i++) samples[i] = (double)tmp[i];
+		}
+		if (e != hipSuccess) rc = fail(c, RTHIP_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+	}
+	(void)hipFree(d_samples);
+	(void)hipFree(d_scratch);
+	return rc;
+}
+
+int32_t rthip_get_stats(rthip_ctx* c, rthip_stats* out) {
+	if (!c || !out) return RTHIP_ERR_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	int32_t rc = collect_stats(c);
+	if (rc != RTHIP_OK) return rc;
+	*out = c->stats;
+	return RTHIP_OK;
+}
+
+int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* ids, int32_t* leaf_sizes, int64_t* n_leaves,
+                             int32_t* depth) {
+	if (n < 0 || (n > 0 && !objects)) return fail(nullptr, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
+	if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
+	FlatScene flat;
+	std::string err;
+	if (!build_flat_scene(objects, n, &flat, &err)) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+	if (ids) std::copy(flat.leaf_ids.begin(), flat.leaf_ids.end(), ids);
+	if (leaf_sizes) std::copy(flat.leaf_sizes.begin(), flat.leaf_sizes.end(), leaf_sizes);
+	if (n_leaves) *n_leaves = (int64_t)flat.leaf_sizes.size();
+	if (depth) *depth = flat.depth;
+	return RTHIP_OK;
+}
+
+int32_t rthip_scene_generate(const char* name, uint32_t seed, rthip_object* out, int64_t capacity, int64_t* n) {
+	if (!name || !n) return fail(nullptr, RTHIP_ERR_INVALID, "name or n is NULL");
+	std::vector<rthip_object> objs;
+	std::string err;
+	if (!generate_scene(name, seed, &objs, &err)) return fail(nullptr, RTHIP_ERR_INVALID, err);
+	*n = (int64_t)objs.size();
+	if (out && capacity > 0) std::memcpy(out, objs.data(), sizeof(rthip_object) * (size_t)std::min<int64_t>(capacity, *n));
+	return RTHIP_OK;
+}
+
+void rthip_camera_rotation(double yaw_deg, double pitch_deg, double out[3]) { camera_rotation(yaw_deg, pitch_deg, out); }
+
+}  // extern "C"

@@ -1,0 +1,479 @@
+// host.cpp — seeded scene factories, Camera::new and the BVH build of librthip (host side).
+// All arithmetic here is f64 with separately rounded operations (-ffp-contract=off), as in
+// the reference's Rust code.
+#include "host.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+namespace rthip {
+
+// ---------------------------------------------------------------------------------------
+// Host-side generator for the scene factories: the PCG RXS-M-XS 32 stream the kernels use,
+// on the fixed stream (pixel = 0xFFFFFFFF, sample = 0).  One draw = one 32-bit word.
+// ---------------------------------------------------------------------------------------
+namespace {
+inline uint32_t mix32(uint32_t x) {
+	x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+	return x;
+}
+struct SceneRng {
+	uint32_t state, inc;
+	explicit SceneRng(uint32_t seed) {
+		uint32_t a = mix32(seed + 0x9E3779B9u * (0xFFFFFFFFu + 1u));
+		uint32_t b = mix32(a ^ (0x85EBCA6Bu * 1u));
+		state = b;
+		inc = (mix32(b + a + 0xC2B2AE35u) << 1) | 1u;
+	}
+	uint32_t next() {
+		uint32_t old = state;
+		state = old * 747796405u + inc;
+		uint32_t word = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
+		return (word >> 22u) ^ word;
+	}
+	double uniform() { return (double)next() * (1.0 / 4294967296.0); }
+	double range(double lo, double hi) { return lo + (hi - lo) * uniform(); }  // src/math.rs:13-15
+};
+
+rthip_object make_sphere(double x, double y, double z, double r, int mat, double ar, double ag, double ab, double param) {
+	rthip_object o;
+	std::memset(&o, 0, sizeof(o));
+	o.kind = RTHIP_SPHERE; o.material = mat;
+	o.center[0] = x; o.center[1] = y; o.center[2] = z;
+	o.extent[0] = r;
+	o.albedo[0] = ar; o.albedo[1] = ag; o.albedo[2] = ab;
+	o.param = param;
+	return o;
+}
+rthip_object make_cube(double x, double y, double z, double hx, double hy, double hz, int mat, double ar, double ag, double ab,
+                       double param) {
+	rthip_object o;
+	std::memset(&o, 0, sizeof(o));
+	o.kind = RTHIP_CUBE; o.material = mat;
+	o.center[0] = x; o.center[1] = y; o.center[2] = z;
+	o.extent[0] = hx; o.extent[1] = hy; o.extent[2] = hz;
+	o.albedo[0] = ar; o.albedo[1] = ag; o.albedo[2] = ab;
+	o.param = param;
+	return o;
+}
+const int L = RTHIP_LAMBERTIAN, M = RTHIP_METAL, D = RTHIP_DIELECTRIC;
+
+// One grid cell of src/scene.rs:158-200 / src/scenes.rs:254-295.  The draw order is the
+// source's: material selector, centre x, centre z, then per branch the albedo components,
+// fuzz, and the sphere-or-cube coin.
+void grid_cell(SceneRng& rng, double cx_base, double y, double cz_base, double size, double inner,
+               std::vector<rthip_object>* spheres, std::vector<rthip_object>* cubes) {
+	double random_mat = rng.range(0.0, 1.0);
+	double cx = cx_base + 0.9 * rng.range(0.0, 1.0);
+	double cz = cz_base + 0.9 * rng.range(0.0, 1.0);
+	double dx = cx - 4.0, dy = y - 0.2, dz = cz - 0.0;
+	if (!(std::sqrt(dx * dx + dy * dy + dz * dz) > 0.9)) return;
+	if (random_mat < 0.35) {  // diffuse: albedo = random * random, emission = the selector itself
+		double a0 = rng.range(0.0, 1.0), a1 = rng.range(0.0, 1.0), a2 = rng.range(0.0, 1.0);
+		double b0 = rng.range(0.0, 1.0), b1 = rng.range(0.0, 1.0), b2 = rng.range(0.0, 1.0);
+		if (rng.range(0.0, 1.0) > 0.5) spheres->push_back(make_sphere(cx, y, cz, size, L, a0 * b0, a1 * b1, a2 * b2, random_mat));
+		else cubes->push_back(make_cube(cx, y, cz, size, size, size, L, a0 * b0, a1 * b1, a2 * b2, random_mat));
+	} else if (random_mat < 0.85) {  // metal
+		double a0 = rng.range(0.5, 1.0), a1 = rng.range(0.5, 1.0), a2 = rng.range(0.5, 1.0);
+		double fuzz = rng.range(0.0, 0.3);
+		if (rng.range(0.0, 1.0) > 0.5) spheres->push_back(make_sphere(cx, y, cz, size, M, a0, a1, a2, fuzz));
+		else cubes->push_back(make_cube(cx, y, cz, size, size, size, M, a0, a1, a2, fuzz));
+	} else {  // glass: an outer shell and an inverted inner one
+		if (rng.range(0.0, 1.0) > 0.5) {
+			spheres->push_back(make_sphere(cx, y, cz, size, D, 0, 0, 0, 1.5));
+			spheres->push_back(make_sphere(cx, y, cz, inner, D, 0, 0, 0, 1.5));
+		} else {
+			cubes->push_back(make_cube(cx, y, cz, size, size, size, D, 0, 0, 0, 1.5));
+			cubes->push_back(make_cube(cx, y, cz, inner, inner, inner, D, 0, 0, 0, 1.5));
+		}
+	}
+}
+
+// Scene::create_sample_scene, src/scene.rs:122-205: one object list in insertion order.
+void scene_default(uint32_t seed, std::vector<rthip_object>* out) {
+	out->push_back(make_cube(0.0, -1000.0, 0.0, 1000.0, 1000.0, 1000.0, L, 0.5, 0.5, 0.5, 0.0));
+	out->push_back(make_sphere(0.0, 1.0, 0.0, 1.0, D, 0, 0, 0, 1.5));
+	out->push_back(make_sphere(0.0, 1.0, 0.0, -0.98, D, 0, 0, 0, 1.5));
+	out->push_back(make_sphere(4.0, 1.0, 0.0, 1.0, L, 0.4, 0.2, 0.1, 3.0));
+	out->push_back(make_sphere(-4.0, 1.0, 0.0, 1.0, M, 0.7, 0.6, 0.5, 0.0));
+	out->push_back(make_sphere(10000.0, 5000.0, 10000.0, 7500.0, L, 0.8, 0.4, 0.2, 60.0));
+	out->push_back(make_cube(-4.0, 0.5, 2.5, 0.8, 0.8, 0.8, L, 0.4, 0.2, 0.1, 3.0));
+	SceneRng rng(seed);
+	for (int a = -11; a < 11; a++)
+		for (int b = -11; b < 11; b++) grid_cell(rng, (double)a, 0.2, (double)b, 0.2, -0.19, out, out);
+}
+// scenes::create_sample_scene, src/scenes.rs:201-300, combined spheres-then-cubes
+// (combine_spheres_and_cubes, src/scenes.rs:5-14): the "many spheres and cubes" scene.
+void scene_sample(uint32_t seed, std::vector<rthip_object>* out) {
+	std::vector<rthip_object> spheres, cubes;
+	cubes.push_back(make_cube(0.0, -100000.0, 0.0, 100000.0, 100000.0, 100000.0, L, 0.5, 0.5, 0.5, 0.0));
+	spheres.push_back(make_sphere(0.0, 1.0, 0.0, 1.0, D, 0, 0, 0, 1.5));
+	spheres.push_back(make_sphere(0.0, 1.0, 0.0, -0.98, D, 0, 0, 0, 1.5));
+	spheres.push_back(make_sphere(4.0, 1.0, 0.0, 1.0, L, 0.4, 0.2, 0.1, 3.0));
+	spheres.push_back(make_sphere(-4.0, 1.0, 0.0, 1.0, M, 0.7, 0.6, 0.5, 0.0));
+	spheres.push_back(make_sphere(10000.0, 5000.0, 10000.0, 7500.0, L, 0.8, 0.4, 0.2, 15.0));
+	cubes.push_back(make_cube(-4.0, 0.5, 2.5, 0.8, 0.8, 0.8, L, 0.4, 0.2, 0.1, 3.0));
+	SceneRng rng(seed);
+	for (int a = -6; a < 6; a++)
+		for (int b = -6; b < 6; b++) grid_cell(rng, 2.0 * (double)a, 0.4, 2.0 * (double)b, 0.4, -0.38, &spheres, &cubes);
+	out->insert(out->end(), spheres.begin(), spheres.end());
+	out->insert(out->end(), cubes.begin(), cubes.end());
+}
+void push_sun_and_ground(std::vector<rthip_object>* spheres, std::vector<rthip_object>* cubes) {
+	spheres->push_back(make_sphere(10000.0, 5000.0, 10000.0, 5000.0, L, 0.8, 0.4, 0.2, 15.0));
+	cubes->push_back(make_cube(0.0, -100002.0, 0.0, 100000.0, 100000.0, 100000.0, L, 0.5, 0.5, 0.5, 0.0));
+}
+void scene_simple(std::vector<rthip_object>* out) {  // src/scenes.rs:17-75
+	std::vector<rthip_object> s, c;
+	s.push_back(make_sphere(0.0, 1.0, -2.0, 0.5, L, 1.0, 0.0, 0.0, 0.5));
+	s.push_back(make_sphere(1.0, 0.5, -3.0, 0.8, M, 0.75, 0.75, 0.75, 0.05));
+	s.push_back(make_sphere(-1.0, -0.5, -4.0, 1.0, M, 0.75, 0.75, 0.75, 0.1));
+	s.push_back(make_sphere(-1.0, 1.0, -4.0, 0.4, M, 0.75, 0.75, 0.75, 0.4));
+	push_sun_and_ground(&s, &c);
+	out->insert(out->end(), s.begin(), s.end());
+	out->insert(out->end(), c.begin(), c.end());
+}
+void scene_glass(std::vector<rthip_object>* out) {  // src/scenes.rs:78-121
+	std::vector<rthip_object> s, c;
+	for (int i = 0; i < 5; i++) {
+		s.push_back(make_sphere((double)i - 5.0, -1.0, -3.0, 0.5, D, 0, 0, 0, 1.5));
+		s.push_back(make_sphere((double)i - 5.0, -1.0, -3.0, -0.49, D, 0, 0, 0, 1.5));
+	}
+	for (int i = 0; i < 5; i++) c.push_back(make_cube(1.5 * (double)i - 5.0, -1.0, -6.0, 0.5, 0.5, 0.5, D, 0, 0, 0, 1.5));
+	push_sun_and_ground(&s, &c);
+	out->insert(out->end(), s.begin(), s.end());
+	out->insert(out->end(), c.begin(), c.end());
+}
+void scene_metal(std::vector<rthip_object>* out) {  // src/scenes.rs:124-170
+	std::vector<rthip_object> s, c;
+	s.push_back(make_sphere(0.0, 1.0, -2.0, 1.5, L, 1.0, 0.0, 0.0, 0.5));
+	s.push_back(make_sphere(10000.0, 10000.0, 10000.0, 2500.0, L, 0.8, 0.4, 0.2, 30.0));
+	c.push_back(make_cube(0.0, -100002.0, 0.0, 100000.0, 100000.0, 100000.0, L, 0.5, 0.5, 0.5, 0.0));
+	for (int i = 0; i < 10; i++) s.push_back(make_sphere((double)i - 5.0, -1.0, -3.0, 0.5, M, 0.75, 0.75, 0.75, (double)i / 10.0));
+	out->insert(out->end(), s.begin(), s.end());
+	out->insert(out->end(), c.begin(), c.end());
+}
+void scene_wallpaper(std::vector<rthip_object>* out) {  // src/scenes.rs:173-198
+	out->push_back(make_sphere(0.0, 0.0, -2.0, 1.0, D, 0, 0, 0, 1.5));
+	out->push_back(make_sphere(0.0, 0.0, -2.0, -0.98, D, 0, 0, 0, 1.5));
+	out->push_back(make_cube(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, L, 0.0, 0.0, 0.0, 0.0));
+}
+// No counterpart in the reference: n objects in all, a ground slab and a sun plus random
+// spheres and cubes, half each, with the default scene's material mix (35 % Lambertian,
+// 50 % metal, 15 % glass) spread over a 1000 x 40 x 1000 volume.
+void scene_synthetic(uint32_t seed, int64_t n, std::vector<rthip_object>* out) {
+	out->reserve((size_t)n);
+	out->push_back(make_cube(0.0, -1000.0, 0.0, 1000.0, 1000.0, 1000.0, L, 0.5, 0.5, 0.5, 0.0));
+	if (n > 1) out->push_back(make_sphere(10000.0, 5000.0, 10000.0, 7500.0, L, 0.8, 0.4, 0.2, 60.0));
+	SceneRng rng(seed);
+	while ((int64_t)out->size() < n) {
+		double sel = rng.uniform();
+		double cx = rng.range(-500.0, 500.0), cy = rng.range(0.2, 40.0), cz = rng.range(-500.0, 500.0);
+		double size = rng.range(0.1, 0.4);
+		bool sphere = rng.uniform() > 0.5;
+		int mat; double a0, a1, a2, param;
+		if (sel < 0.35) { mat = L; a0 = rng.uniform() * rng.uniform(); a1 = rng.uniform() * rng.uniform(); a2 = rng.uniform() * rng.uniform(); param = 0.0; }
+		else if (sel < 0.85) { mat = M; a0 = rng.range(0.5, 1.0); a1 = rng.range(0.5, 1.0); a2 = rng.range(0.5, 1.0); param = rng.range(0.0, 0.3); }
+		else { mat = D; a0 = a1 = a2 = 0.0; param = 1.5; }
+		if (sphere) out->push_back(make_sphere(cx, cy, cz, size, mat, a0, a1, a2, param));
+		else out->push_back(make_cube(cx, cy, cz, size, size, size, mat, a0, a1, a2, param));
+	}
+}
+}  // namespace
+
+bool generate_scene(const std::string& name, uint32_t seed, std::vector<rthip_object>* out, std::string* err) {
+	out->clear();
+	if (name == "default") scene_default(seed, out);
+	else if (name == "sample") scene_sample(seed, out);
+	else if (name == "simple") scene_simple(out);
+	else if (name == "glass") scene_glass(out);
+	else if (name == "metal") scene_metal(out);
+	else if (name == "wallpaper") scene_wallpaper(out);
+	else if (name.rfind("synthetic:", 0) == 0) {
+		char* end = nullptr;
+		long long n = std::strtoll(name.c_str() + 10, &end, 10);
+		if (n < 1 || n > kMaxObjects || (end && *end)) { *err = "synthetic:N needs 1 <= N <= 2^25"; return false; }
+		scene_synthetic(seed, (int64_t)n, out);
+	} else {
+		*err = "unknown scene '" + name + "'";
+		return false;
+	}
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// Camera::new, src/camera.rs:25-69, operation for operation.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct V3 { double x, y, z; };
+inline V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator/(V3 a, double s) { return v3(a.x / s, a.y / s, a.z / s); }
+inline V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline V3 unit(V3 a) { double l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return v3(a.x / l, a.y / l, a.z / l); }
+inline double to_radians(double deg) { return deg * M_PI / 180.0; }  // src/math.rs:8-10
+inline void put(double* d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+}  // namespace
+
+CameraFields camera_new(const rthip_camera_desc& d) {
+	const V3 world_up = v3(0.0, 1.0, 0.0);
+	V3 origin = v3(d.origin[0], d.origin[1], d.origin[2]);
+	V3 direction = v3(d.direction[0], d.direction[1], d.direction[2]);
+	double theta = to_radians(d.fov);
+	double h = std::tan(theta / 2.0);
+	double viewport_height = 2.0 * h * d.focus_dist;
+	double viewport_width = viewport_height * ((double)d.width / (double)d.height);
+	V3 w = -unit(direction);
+	V3 u = unit(cross(world_up, w));
+	V3 v = cross(w, u);
+	V3 viewport_u = u * viewport_width;
+	V3 viewport_v = (-v) * viewport_height;
+	V3 delta_x = viewport_u / (double)d.width;
+	V3 delta_y = viewport_v / (double)d.height;
+	V3 upper_left = origin - (w * d.focus_dist) - viewport_u / 2.0 - viewport_v / 2.0;
+	V3 pixel00 = upper_left + (delta_x + delta_y) * 0.5;
+	double defocus_radius = d.focus_dist * std::tan(to_radians(d.defocus_angle / 2.0));
+	CameraFields c;
+	put(c.origin, origin); put(c.pixel00, pixel00); put(c.delta_x, delta_x); put(c.delta_y, delta_y);
+	put(c.disk_x, u * defocus_radius); put(c.disk_y, v * defocus_radius);
+	c.defocus_angle = d.defocus_angle;
+	c.width = d.width; c.height = d.height;
+	return c;
+}
+void camera_rotation(double yaw_deg, double pitch_deg, double out[3]) {  // src/camera.rs:95-103
+	double pitch = pitch_deg * (M_PI / 180.0), yaw = yaw_deg * (M_PI / 180.0);
+	out[0] = std::cos(yaw) * std::cos(pitch);
+	out[1] = std::sin(pitch);
+	out[2] = std::sin(yaw) * std::cos(pitch);
+}
+
+// ---------------------------------------------------------------------------------------
+// BVH::new, src/bvh.rs:17-81, built over an index array and written out flat.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct Box { double lo[3], hi[3]; };
+inline Box box_union(const Box& a, const Box& b) {
+	Box r;
+	for (int k = 0; k < 3; k++) { r.lo[k] = std::fmin(a.lo[k], b.lo[k]); r.hi[k] = std::fmax(a.hi[k], b.hi[k]); }
+	return r;
+}
+inline float round_down(double v) { float f = (float)v; return ((double)f > v) ? std::nextafterf(f, -INFINITY) : f; }
+inline float round_up(double v) { float f = (float)v; return ((double)f < v) ? std::nextafterf(f, INFINITY) : f; }
+
+struct Builder {
+	const rthip_object* objs;
+	std::vector<int32_t> order;  // object ids, permuted in place by the per-level sorts
+	FlatScene* out;
+	int max_depth = 0;
+
+	// The box the reference caches per object (src/shapes/sphere.rs:19, cube.rs:17): centre
+	// -/+ radius or half extent AS GIVEN, so it is inverted for negative sizes.  Used for the
+	// split axis and the sort key only, exactly as src/bvh.rs:18-43 uses it.
+	double ref_min(int32_t id, int axis) const {
+		const rthip_object& o = objs[id];
+		return o.center[axis] - (o.kind == RTHIP_SPHERE ? o.extent[0] : o.extent[axis]);
+	}
+	double ref_max(int32_t id, int axis) const {
+		const rthip_object& o = objs[id];
+		return o.center[axis] + (o.kind == RTHIP_SPHERE ? o.extent[0] : o.extent[axis]);
+	}
+	// True bounds of the primitive as each precision stores it.
+	Box bounds64(int32_t id) const {
+		const rthip_object& o = objs[id];
+		Box b;
+		for (int k = 0; k < 3; k++) {
+			double e = std::fabs(o.kind == RTHIP_SPHERE ? o.extent[0] : o.extent[k]);
+			b.lo[k] = o.center[k] - e; b.hi[k] = o.center[k] + e;
+		}
+		return b;
+	}
+	Box bounds32(int32_t id) const {
+		const rthip_object& o = objs[id];
+		Box b;
+		for (int k = 0; k < 3; k++) {
+			if (o.kind == RTHIP_SPHERE) {
+				double c = (double)(float)o.center[k], r = std::fabs((double)(float)o.extent[0]);
+				b.lo[k] = c - r; b.hi[k] = c + r;
+			} else {
+				double lo = (double)(float)(o.center[k] - o.extent[k]), hi = (double)(float)(o.center[k] + o.extent[k]);
+				b.lo[k] = std::fmin(lo, hi); b.hi[k] = std::fmax(lo, hi);
+			}
+		}
+		return b;
+	}
+
+	// Box of the object as the reference caches it (inverted for negative sizes).
+	Box ref_box(int32_t id) const {
+		Box b;
+		for (int k = 0; k < 3; k++) { b.lo[k] = ref_min(id, k); b.hi[k] = ref_max(id, k); }
+		return b;
+	}
+
+	struct Sub { int32_t code; Box b64, b32, ref; };
+
+	// Index of a new gate when the reference's box differs from the true bounds, else -1.
+	int32_t gate_for(const Sub& s) {
+		bool same = true;
+		for (int k = 0; k < 3; k++) same = same && s.ref.lo[k] == s.b64.lo[k] && s.ref.hi[k] == s.b64.hi[k];
+		if (same) return -1;
+		Gate<double> g64;
+		Gate<float> g32;
+		for (int k = 0; k < 3; k++) {
+			g64.box[k] = s.ref.lo[k]; g64.box[3 + k] = s.ref.hi[k];
+			g32.box[k] = (float)s.ref.lo[k]; g32.box[3 + k] = (float)s.ref.hi[k];
+		}
+		out->gates64.push_back(g64);
+		out->gates32.push_back(g32);
+		return (int32_t)out->gates64.size() - 1;
+	}
+
+	Sub build(size_t begin, size_t end, int depth) {
+		size_t len = end - begin;
+		// src/bvh.rs:28-47: the axis of largest extent of the cached boxes; the first such axis
+		// on ties (sort_unstable_by leaves that open; a three-element sort keeps input order).
+		int axis = 0;
+		double best_range = 0;
+		for (int a = 0; a < 3; a++) {
+			double bmin = DBL_MAX, bmax = -DBL_MAX;
+			for (size_t i = begin; i < end; i++) {
+				bmin = std::fmin(bmin, ref_min(order[i], a));
+				bmax = std::fmax(bmax, ref_max(order[i], a));
+			}
+			double range = bmax - bmin;
+			if (a == 0 || range > best_range) { axis = a; best_range = range; }
+		}
+		// src/bvh.rs:18-26,49: ascending by min+max on that axis.  Equal keys keep their current
+		// order (the reference's unstable sort leaves it unspecified).
+		std::stable_sort(order.begin() + (long)begin, order.begin() + (long)end, [this, axis](int32_t a, int32_t b) {
+			return (ref_min(a, axis) + ref_max(a, axis)) < (ref_min(b, axis) + ref_max(b, axis));
+		});
+		if (len < 6) return emit_leaf(begin, end, depth);  // src/bvh.rs:52-61
+		// src/bvh.rs:62-79: the upper half is the right child.
+		size_t mid = begin + len / 2;
+		int32_t me = (int32_t)out->nodes64.size();
+		out->nodes64.emplace_back();
+		out->nodes32.emplace_back();
+		Sub l = build(begin, mid, depth + 1);
+		Sub r = build(mid, end, depth + 1);
+		write_node(me, l, r);
+		if (depth + 1 > max_depth) max_depth = depth + 1;
+		return Sub{me, box_union(l.b64, r.b64), box_union(l.b32, r.b32), box_union(l.ref, r.ref)};
+	}
+
+	void write_node(int32_t me, const Sub& l, const Sub& r) {
+		Node<double>& n64 = out->nodes64[(size_t)me];
+		Node<float>& n32 = out->nodes32[(size_t)me];
+		const Sub* ch[2] = {&l, &r};
+		for (int c = 0; c < 2; c++) {
+			for (int k = 0; k < 3; k++) {
+				n64.box[6 * c + k] = ch[c]->b64.lo[k];
+				n64.box[6 * c + 3 + k] = ch[c]->b64.hi[k];
+				n32.box[6 * c + k] = round_down(ch[c]->b32.lo[k]);
+				n32.box[6 * c + 3 + k] = round_up(ch[c]->b32.hi[k]);
+			}
+			n64.child[c] = ch[c]->code;
+			n32.child[c] = ch[c]->code;
+			n64.gate[c] = n32.gate[c] = gate_for(*ch[c]);
+		}
+	}
+
+	Sub emit_leaf(size_t begin, size_t end, int depth) {
+		(void)depth;
+		int k = (int)(end - begin);
+		int32_t first = (int32_t)out->prims64.size();
+		int32_t rank_base = first;  // primitives are appended leaf by leaf, left to right
+		Box b64 = bounds64(order[begin]), b32 = bounds32(order[begin]), ref = ref_box(order[begin]);
+		int ns = 0, nc = 0;
+		// Spheres first, then cubes; the rank keeps the reference's tie rule whatever the
+		// storage order: leaves rank left to right, objects inside a leaf in reverse
+		// (the first object of a leaf wins a tie, src/scene.rs:105; the right child wins a
+		// tie between siblings, src/bvh.rs:98-104).
+		for (int pass = 0; pass < 2; pass++) {
+			for (int j = 0; j < k; j++) {
+				int32_t id = order[begin + (size_t)j];
+				const rthip_object& o = objs[id];
+				if ((o.kind == RTHIP_SPHERE) != (pass == 0)) continue;
+				if (pass == 0) ns++; else nc++;
+				Prim<double> p64;
+				Prim<float> p32;
+				for (int q = 0; q < 6; q++) { p64.v[q] = 0.0; p32.v[q] = 0.0f; }
+				for (int q = 0; q < 3; q++) { p64.v[q] = o.center[q]; p32.v[q] = (float)o.center[q]; }
+				if (o.kind == RTHIP_SPHERE) {
+					p64.v[3] = o.extent[0];
+					p32.v[3] = (float)o.extent[0];
+				} else {
+					for (int q = 0; q < 3; q++) {
+						p64.v[3 + q] = o.extent[q];
+						p32.v[q] = (float)(o.center[q] - o.extent[q]);
+						p32.v[3 + q] = (float)(o.center[q] + o.extent[q]);
+					}
+				}
+				p64.id = p32.id = id | (o.material << kMatShift) | (o.kind << kKindShift);
+				p64.rank = p32.rank = rank_base + (k - 1 - j);
+				out->prims64.push_back(p64);
+				out->prims32.push_back(p32);
+			}
+		}
+		for (int j = 0; j < k; j++) {
+			int32_t id = order[begin + (size_t)j];
+			out->leaf_ids.push_back(id);
+			if (j > 0) { b64 = box_union(b64, bounds64(id)); b32 = box_union(b32, bounds32(id)); ref = box_union(ref, ref_box(id)); }
+		}
+		out->leaf_sizes.push_back(k);
+		out->n_leaves++;
+		return Sub{leaf_code(first, ns, nc), b64, b32, ref};
+	}
+};
+}  // namespace
+
+bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err) {
+	*out = FlatScene();
+	if (n <= 0) { *err = "empty scene: BVH::new returns None"; return false; }
+	if (n > kMaxObjects) { *err = "too many objects"; return false; }
+	for (int64_t i = 0; i < n; i++) {
+		const rthip_object& o = objs[i];
+		bool ok = (o.kind == RTHIP_SPHERE || o.kind == RTHIP_CUBE) && o.material >= 0 && o.material <= 2 && std::isfinite(o.param);
+		for (int k = 0; k < 3; k++) ok = ok && std::isfinite(o.center[k]) && std::isfinite(o.albedo[k]) && (o.kind == RTHIP_SPHERE ? std::isfinite(o.extent[0]) : std::isfinite(o.extent[k]));
+		if (!ok) { *err = "object " + std::to_string(i) + " has an invalid kind, material or a non-finite field"; return false; }
+	}
+	Builder b;
+	b.objs = objs;
+	b.out = out;
+	b.order.resize((size_t)n);
+	std::iota(b.order.begin(), b.order.end(), 0);
+	out->mats64.resize((size_t)n);
+	out->mats32.resize((size_t)n);
+	for (int64_t i = 0; i < n; i++) {
+		for (int k = 0; k < 3; k++) { out->mats64[(size_t)i].albedo[k] = objs[i].albedo[k]; out->mats32[(size_t)i].albedo[k] = (float)objs[i].albedo[k]; }
+		out->mats64[(size_t)i].param = objs[i].param;
+		out->mats32[(size_t)i].param = (float)objs[i].param;
+	}
+	if (n < 6) {
+		// The whole scene is one leaf: give the kernels a root whose left child is that leaf
+		// and whose right child is an empty leaf behind a box no ray can enter.
+		out->nodes64.emplace_back();
+		out->nodes32.emplace_back();
+		// sort as the reference does even for a single leaf (src/bvh.rs:49 runs before the match)
+		Builder::Sub l = b.build(0, (size_t)n, 0);
+		Builder::Sub r;
+		r.code = leaf_code(0, 0, 0);
+		for (int k = 0; k < 3; k++) { r.b64.lo[k] = r.b32.lo[k] = r.ref.lo[k] = INFINITY; r.b64.hi[k] = r.b32.hi[k] = r.ref.hi[k] = -INFINITY; }
+		b.write_node(0, l, r);  // the leaf's gate, if any, is the root's
+		out->depth = 1;
+	} else {
+		Builder::Sub root = b.build(0, (size_t)n, 0);
+		out->root_gate = b.gate_for(root);
+		out->depth = b.max_depth;
+	}
+	if (out->depth > kStackMax) { *err = "tree deeper than the traversal stack"; return false; }
+	return true;
+}
+
+}  // namespace rthip

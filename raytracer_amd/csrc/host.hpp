@@ -1,0 +1,46 @@
+// host.hpp — host-side half of librthip: seeded scene factories, Camera::new, and the
+// reference-shaped BVH build flattened into the arrays the kernels read.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rthip.h"
+#include "layout.hpp"
+
+namespace rthip {
+
+// ---- scene factories -------------------------------------------------------------------
+// Returns false when `name` is unknown.
+bool generate_scene(const std::string& name, uint32_t seed, std::vector<rthip_object>* out, std::string* err);
+
+// ---- camera (src/camera.rs:25-69) --------------------------------------------------------
+struct CameraFields {
+	double origin[3], pixel00[3], delta_x[3], delta_y[3], disk_x[3], disk_y[3];
+	double defocus_angle;
+	int width, height;
+};
+CameraFields camera_new(const rthip_camera_desc& d);
+void camera_rotation(double yaw_deg, double pitch_deg, double out[3]);
+
+// ---- BVH (src/bvh.rs:17-81) --------------------------------------------------------------
+struct FlatScene {
+	// Both precisions of every array, ready to copy to the device.
+	std::vector<Node<float>> nodes32;
+	std::vector<Prim<float>> prims32;
+	std::vector<Mat<float>> mats32;
+	std::vector<Gate<float>> gates32;
+	std::vector<Node<double>> nodes64;
+	std::vector<Prim<double>> prims64;
+	std::vector<Mat<double>> mats64;
+	std::vector<Gate<double>> gates64;
+	int root_gate = -1;  // gate of the root itself, or -1
+	int depth = 0;     // levels of inner nodes on the longest root-to-leaf path
+	int n_leaves = 0;
+	std::vector<int32_t> leaf_ids;    // object ids, leaves left to right, reference order inside a leaf
+	std::vector<int32_t> leaf_sizes;
+};
+// Returns false (with a message) for an empty scene or non-finite input.
+bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err);
+
+}  // namespace rthip

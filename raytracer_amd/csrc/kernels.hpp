@@ -1,0 +1,702 @@
+// kernels.hpp — the path-tracing hot path as gfx950 device code, templated on the arithmetic
+// type.  Instantiated twice: kernels_f32.hip (production; compiled with fp contraction) and
+// kernels_f64.hip (the reference's own f64 arithmetic, operation for operation, compiled with
+// -ffp-contract=off so that results can be compared bit for bit with a CPU restatement).
+//
+// What replaces what (reference file:line):
+//   camera_ray        Camera::get_ray                     src/camera.rs:72-92
+//   hit_sphere/_cube  Sphere::hit, Cube::hit              src/shapes/sphere.rs:26-48, cube.rs:24-42
+//   Traversal         BVH::hit + Scene::hit               src/bvh.rs:84-127, src/scene.rs:100-113
+//   make_hit          BVH::trace, get_normal              src/bvh.rs:130-142, sphere.rs:60-62, cube.rs:54-64
+//   scatter           Material::scatter / reflectance     src/materials.rs:17-85
+//   sky               Scene::get_sky_color                src/scene.rs:116-120
+//   render_kernel     render() + ray_color() + the sample loop
+//                                                         src/renderer.rs:3-40, raytracer_headless/src/main.rs:41-55
+//
+// Execution model.  One launch renders `spp_count` samples of every pixel the call owns.  The
+// grid is persistent: every wave pulls work items (an 8x8 tile x `chunk` samples = 64*chunk
+// paths) from a global counter and keeps its 64 lanes busy by handing a finished lane the next
+// path of the wave's pool (ballot + mbcnt ranking), so lanes are not tied to pixels.  A lane is
+// a small state machine: IDLE -> TRAVERSE -> SHADE -> (TRAVERSE | IDLE).  The wave alternates
+// between a traversal loop, which it leaves once the number of lanes still traversing drops
+// under a threshold while other lanes wait, and a shading/regeneration step; lanes interrupted
+// mid-traversal keep their stack and simply continue on the next round.  The per-lane
+// traversal stack lives in LDS ([entry][thread], conflict-free); scenes that fit are copied to
+// LDS as well, so the inner loop touches no global memory.  Finished paths add sqrt(radiance)
+// to the accumulation buffer as 64-bit fixed-point integers (atomic adds commute exactly, so
+// the image does not depend on scheduling, on the tile partition or on the GPU count).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "layout.hpp"
+
+namespace rthip {
+
+constexpr int kBlock = 256;
+constexpr int kDone = INT32_MIN;  // traversal finished (not a valid leaf code)
+
+template <typename Real>
+struct RenderArgs {
+	const char* scene;  // [nodes | prims | mats | gates] blob in HBM, each part 64-byte aligned
+	uint32_t prims_off, mats_off, gates_off, scene_bytes;
+	int32_t root_gate;      // gate of the root itself, or -1
+	int32_t stack_entries;  // tree depth
+	CameraT<Real> cam;
+	int32_t width, height, tiles_x, tiles_y;
+	uint32_t spp_begin, spp_count;
+	int32_t max_depth;
+	uint32_t seed;
+	int32_t sky_mode;
+	int32_t part_index, part_count;
+	uint32_t n_items, chunk, n_chunks;
+	int32_t trav_threshold;
+	unsigned long long* accum;    // [tiles][64][4] fixed point
+	Real* samples_out;            // optional [spp_count][H][W][3]
+	uint32_t* queue;              // work-item counter, zeroed before the launch
+	unsigned long long* stats;    // [0] paths [1] rays [2] box tests [3] sphere tests [4] cube tests
+};
+
+template <typename Real>
+struct ProbeArgs {
+	const char* scene;
+	uint32_t prims_off, mats_off, gates_off, scene_bytes;
+	int32_t root_gate;
+	int32_t stack_entries;
+	CameraT<Real> cam;
+	int32_t width, height;
+	uint32_t seed, sample;
+	int32_t jitter;
+	int32_t* id;
+	double* t;
+	double* normal;
+	uint8_t* front;
+};
+
+// ---------------------------------------------------------------------------------------
+// Arithmetic policy.  f64 follows the reference literally.  f32 uses the hardware's 1-ulp
+// reciprocal / square root / reciprocal square root.
+// ---------------------------------------------------------------------------------------
+template <typename Real> struct Fp;
+template <> struct Fp<float> {
+	static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+	static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+	static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+	static __device__ __forceinline__ float uniform(uint32_t r) { return (float)(r >> 8) * 0x1p-24f; }
+	static __device__ __forceinline__ float fmin(float a, float b) { return __builtin_fminf(a, b); }
+	static __device__ __forceinline__ float fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+	static __device__ __forceinline__ float fabs(float a) { return __builtin_fabsf(a); }
+	static __device__ __forceinline__ float copysign(float a, float b) { return __builtin_copysignf(a, b); }
+	static __device__ __forceinline__ float inf() { return __builtin_inff(); }
+};
+template <> struct Fp<double> {
+	static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+	static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
+	static __device__ __forceinline__ double uniform(uint32_t r) { return (double)r * (1.0 / 4294967296.0); }
+	static __device__ __forceinline__ double fmin(double a, double b) { return __builtin_fmin(a, b); }
+	static __device__ __forceinline__ double fmax(double a, double b) { return __builtin_fmax(a, b); }
+	static __device__ __forceinline__ double fabs(double a) { return __builtin_fabs(a); }
+	static __device__ __forceinline__ double copysign(double a, double b) { return __builtin_copysign(a, b); }
+	static __device__ __forceinline__ double inf() { return __builtin_inf(); }
+};
+
+// src/math.rs:18-318
+template <typename Real> struct V3 { Real x, y, z; };
+#define RT_FN template <typename Real> __device__ __forceinline__
+RT_FN V3<Real> mk(Real x, Real y, Real z) { return V3<Real>{x, y, z}; }
+RT_FN V3<Real> ld3(const Real* p) { return V3<Real>{p[0], p[1], p[2]}; }
+RT_FN V3<Real> operator+(V3<Real> a, V3<Real> b) { return mk<Real>(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_FN V3<Real> operator-(V3<Real> a, V3<Real> b) { return mk<Real>(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_FN V3<Real> operator-(V3<Real> a) { return mk<Real>(-a.x, -a.y, -a.z); }
+RT_FN V3<Real> operator*(V3<Real> a, Real s) { return mk<Real>(a.x * s, a.y * s, a.z * s); }
+RT_FN V3<Real> operator*(Real s, V3<Real> a) { return mk<Real>(a.x * s, a.y * s, a.z * s); }
+RT_FN V3<Real> operator*(V3<Real> a, V3<Real> b) { return mk<Real>(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_FN V3<Real> operator/(V3<Real> a, Real s) { return mk<Real>(a.x / s, a.y / s, a.z / s); }
+RT_FN Real dot(V3<Real> a, V3<Real> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_FN Real length_squared(V3<Real> a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+// src/math.rs:78-85: divide by the length (f64); f32 multiplies by the reciprocal square root.
+RT_FN V3<Real> normalize(V3<Real> a) {
+	if constexpr (std::is_same<Real, float>::value) {
+		return a * Fp<float>::rsqrt(length_squared(a));
+	} else {
+		Real l = Fp<Real>::sqrt(length_squared(a));
+		return mk<Real>(a.x / l, a.y / l, a.z / l);
+	}
+}
+// src/math.rs:97-99: v - ((n * 2) * dot(v, n))
+RT_FN V3<Real> reflect(V3<Real> v, V3<Real> n) { return v - ((n * Real(2)) * dot(v, n)); }
+// src/math.rs:102-107
+RT_FN V3<Real> refract(V3<Real> uv, V3<Real> n, Real eta) {
+	Real cos_theta = Fp<Real>::fmin(dot(-uv, n), Real(1));
+	V3<Real> perp = eta * (uv + cos_theta * n);
+	V3<Real> par = -(Fp<Real>::sqrt(Fp<Real>::fabs(Real(1) - length_squared(perp)))) * n;
+	return perp + par;
+}
+
+// ---------------------------------------------------------------------------------------
+// Counter-based random stream: PCG RXS-M-XS 32 whose state and increment are hashed from
+// (seed, pixel index, sample index).  One draw is one 32-bit word; f32 uses its top 24 bits,
+// f64 all 32, so both precisions walk the same stream.  The reference's generator is
+// OS-seeded (src/math.rs:13-15, raytracer_headless/src/main.rs:40): only distributions and
+// draw counts are contractual.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+	x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+	return x;
+}
+struct Rng {
+	uint32_t state, inc;
+	__device__ __forceinline__ void init(uint32_t seed, uint32_t pixel, uint32_t sample) {
+		uint32_t a = mix32(seed + 0x9E3779B9u * (pixel + 1u));
+		uint32_t b = mix32(a ^ (0x85EBCA6Bu * (sample + 1u)));
+		state = b;
+		inc = (mix32(b + a + 0xC2B2AE35u) << 1) | 1u;
+	}
+	__device__ __forceinline__ uint32_t next() {
+		uint32_t old = state;
+		state = old * 747796405u + inc;
+		uint32_t word = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
+		return (word >> 22u) ^ word;
+	}
+};
+// src/math.rs:13-15 random(min, max): half-open, uniform * scale + low
+RT_FN Real random_range(Real lo, Real hi, Rng& r) { return lo + (hi - lo) * Fp<Real>::uniform(r.next()); }
+// src/math.rs:156-168: three draws x, y, z in [-1, 1), normalised (a cube sample pushed to
+// the sphere, not uniform on it: kept as written).
+RT_FN V3<Real> random_unit_vector(Rng& r) {
+	Real x = random_range<Real>(Real(-1), Real(1), r);
+	Real y = random_range<Real>(Real(-1), Real(1), r);
+	Real z = random_range<Real>(Real(-1), Real(1), r);
+	return normalize(mk<Real>(x, y, z));
+}
+
+template <typename Real> struct RayT {
+	V3<Real> o, d;
+};
+
+// src/camera.rs:83-92 (+ :72-81).  Draws: jitter x, jitter y, then disk x, disk y only when
+// defocus_angle > 0.  The disk sample is normalised onto the unit circle (src/math.rs:171-174)
+// and the two scaled basis vectors are MULTIPLIED component-wise (src/camera.rs:80): both are
+// the reference's behaviour and are kept.
+RT_FN RayT<Real> camera_ray(const CameraT<Real>& c, Real x, Real y, Rng& rng, bool jitter) {
+	V3<Real> origin = ld3(c.origin), dx = ld3(c.delta_x), dy = ld3(c.delta_y);
+	V3<Real> pixel_center = ld3(c.pixel00) + (dx * x) + (dy * y);
+	if (!jitter) return RayT<Real>{origin, normalize(pixel_center - origin)};
+	Real jx = random_range<Real>(Real(-0.5), Real(0.5), rng);
+	Real jy = random_range<Real>(Real(-0.5), Real(0.5), rng);
+	V3<Real> pixel_sample = pixel_center + ((jx * dx) + (jy * dy));
+	V3<Real> ray_origin = origin;
+	if (c.defocus_angle > Real(0)) {
+		Real px = random_range<Real>(Real(-1), Real(1), rng);
+		Real py = random_range<Real>(Real(-1), Real(1), rng);
+		V3<Real> p = normalize(mk<Real>(px, py, Real(0)));
+		ray_origin = origin + (p.x * ld3(c.disk_x)) * (p.y * ld3(c.disk_y));
+	}
+	return RayT<Real>{ray_origin, normalize(pixel_sample - ray_origin)};
+}
+
+// src/scene.rs:116-120, and the wallpaper sky (formula of
+// raytracer_gpu/src/shaders/compute.wgsl:186-195 on the normalised direction).
+RT_FN V3<Real> sky(V3<Real> dir, int sky_mode) {
+	V3<Real> u = normalize(dir);
+	if (sky_mode == RTHIP_SKY_WALLPAPER) {
+		Real strength = Real(0.5) * (-u.y + Real(0.25));
+		Real t = Real(0.5) * (u.x + Real(1));
+		Real e = Real(2) * t - Real(1);
+		Real pw;
+		if constexpr (std::is_same<Real, float>::value) pw = __builtin_exp2f(6.62935662f * (e * e - 1.0f));  // 99^x
+		else pw = ::pow(99.0, e * e - 1.0);
+		strength *= Real(50) * pw;
+		V3<Real> a = mk<Real>(Real(0.94), Real(0.02), Real(0.99)), b = mk<Real>(Real(0), Real(0.85), Real(0.98));
+		V3<Real> c = mk<Real>(Real(0), Real(0.45), Real(0.98)), d = mk<Real>(Real(0), Real(0.98), Real(0.45));
+		return (a * (Real(1) - t) + b * t) * strength + (Real(0.25) * c) * (Real(0.5) * (u.y + Real(1))) +
+		       (Real(0.15) * d) * (Real(0.5) * (-u.x + Real(1)));
+	}
+	Real a = Real(0.5) * (u.y + Real(1));
+	return mk<Real>(Real(1), Real(1), Real(1)) * (Real(1) - a) + mk<Real>(Real(0.5), Real(0.7), Real(1)) * a;
+}
+
+// ---------------------------------------------------------------------------------------
+// A ray prepared for traversal.
+// ---------------------------------------------------------------------------------------
+template <typename Real> struct TravRay {
+	V3<Real> o, d, inv;  // inv = 1 / d
+	Real a, rcp_a;       // d.d and its reciprocal (f32 sphere test)
+};
+RT_FN TravRay<Real> prepare(RayT<Real> r) {
+	TravRay<Real> t;
+	t.o = r.o; t.d = r.d;
+	t.inv = mk<Real>(Fp<Real>::rcp(r.d.x), Fp<Real>::rcp(r.d.y), Fp<Real>::rcp(r.d.z));
+	t.a = dot(r.d, r.d);
+	t.rcp_a = Fp<Real>::rcp(t.a);
+	return t;
+}
+
+// Sphere::hit, src/shapes/sphere.rs:26-48: the NEAR root only, direction not assumed unit.
+// f64: the reference's quadratic, literally.  f32: the same root written as
+//   t = (-(oc.d) - sqrt(a * (r^2 - |oc - ((oc.d)/a) d|^2))) / a
+// which keeps the discriminant accurate when |oc| >> r (small spheres far away, or the sun
+// sphere of radius 7500): b^2 - 4ac = 4a (r^2 - |q|^2) with q the closest approach to the centre.
+RT_FN bool hit_sphere(const Prim<Real>& s, const TravRay<Real>& r, Real* t) {
+	V3<Real> oc = r.o - ld3(s.v);
+	Real radius = s.v[3];
+	if constexpr (std::is_same<Real, float>::value) {
+		Real b = dot(oc, r.d);
+		V3<Real> q = oc - (b * r.rcp_a) * r.d;
+		Real disc = radius * radius - dot(q, q);
+		if (disc < 0.0f) return false;
+		*t = (-b - Fp<float>::sqrt(r.a * disc)) * r.rcp_a;
+		return true;
+	} else {
+		Real a = dot(r.d, r.d);
+		Real b = 2.0 * dot(oc, r.d);
+		Real c = dot(oc, oc) - radius * radius;
+		Real discriminant = b * b - 4.0 * a * c;
+		if (discriminant < 0.0) return false;
+		*t = (-b - Fp<double>::sqrt(discriminant)) / (2.0 * a);
+		return true;
+	}
+}
+// Cube::hit, src/shapes/cube.rs:24-42: entry distance from OUTSIDE only (t_n <= 0 -> None),
+// a negative half extent never hits.  f64: the reference's centre/half-extent form.  f32: the
+// same planes stored as lo = c - he, hi = c + he (rounded once from f64): per axis the near
+// plane is lo when d >= 0 else hi, which is -n - k of the reference in exact arithmetic,
+// without the cancellation of (o - c) against he for slabs of half extent 1e3..1e5.
+RT_FN bool hit_cube(const Prim<Real>& c, const TravRay<Real>& r, Real* t) {
+	Real t_n, t_f;
+	if constexpr (std::is_same<Real, float>::value) {
+		float ax = (c.v[0] - r.o.x) * r.inv.x, bx = (c.v[3] - r.o.x) * r.inv.x;
+		float ay = (c.v[1] - r.o.y) * r.inv.y, by = (c.v[4] - r.o.y) * r.inv.y;
+		float az = (c.v[2] - r.o.z) * r.inv.z, bz = (c.v[5] - r.o.z) * r.inv.z;
+		bool nx = r.inv.x < 0.0f, ny = r.inv.y < 0.0f, nz = r.inv.z < 0.0f;
+		t_n = Fp<float>::fmax(Fp<float>::fmax(nx ? bx : ax, ny ? by : ay), nz ? bz : az);
+		t_f = Fp<float>::fmin(Fp<float>::fmin(nx ? ax : bx, ny ? ay : by), nz ? az : bz);
+	} else {
+		V3<Real> origin = r.o - ld3(c.v);
+		V3<Real> m = mk<Real>(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+		V3<Real> n = m * origin;
+		V3<Real> k = mk<Real>(Fp<Real>::fabs(m.x), Fp<Real>::fabs(m.y), Fp<Real>::fabs(m.z)) * ld3(c.v + 3);
+		V3<Real> t1 = -n - k;
+		V3<Real> t2 = -n + k;
+		t_n = Fp<Real>::fmax(Fp<Real>::fmax(t1.x, t1.y), t1.z);
+		t_f = Fp<Real>::fmin(Fp<Real>::fmin(t2.x, t2.y), t2.z);
+	}
+	if (t_n > t_f || t_f <= Real(0) || t_n <= Real(0)) return false;
+	*t = t_n;
+	return true;
+}
+
+// True slab test of one child box against (0.001, best_t].  The box distances and a primitive's
+// own t round differently (a cube's face and the face of the box around it are one plane
+// computed by two formulas), so the far side and the best_t bound are widened by a pad:
+// culling stays conservative, and two coplanar faces of different leaves still meet in the
+// (t, rank) comparison.  f32: 2^-18; f64: 2^-30 (covers the cancellation of the reference's
+// centre/half-extent cube formula for slabs of half extent 1e5).
+RT_FN bool hit_box(const Real* b, const TravRay<Real>& r, Real best_t, Real* entry) {
+	Real tx0 = (b[0] - r.o.x) * r.inv.x, tx1 = (b[3] - r.o.x) * r.inv.x;
+	Real ty0 = (b[1] - r.o.y) * r.inv.y, ty1 = (b[4] - r.o.y) * r.inv.y;
+	Real tz0 = (b[2] - r.o.z) * r.inv.z, tz1 = (b[5] - r.o.z) * r.inv.z;
+	Real tnear = Fp<Real>::fmax(Fp<Real>::fmax(Fp<Real>::fmin(tx0, tx1), Fp<Real>::fmin(ty0, ty1)), Fp<Real>::fmin(tz0, tz1));
+	Real tfar = Fp<Real>::fmin(Fp<Real>::fmin(Fp<Real>::fmax(tx0, tx1), Fp<Real>::fmax(ty0, ty1)), Fp<Real>::fmax(tz0, tz1));
+	*entry = tnear;
+	const Real pad = std::is_same<Real, float>::value ? Real(1.0 + 0x1p-18) : Real(1.0 + 0x1p-30);
+	tfar = tfar * pad;
+	return tnear <= tfar && tfar > Real(0.001) && tnear <= best_t * pad;
+}
+
+// AABB::hit, src/math.rs:356-371, as written: every axis is clipped against the constants
+// [0.001, MAX] on its own (the interval is not carried from axis to axis).  Only used on gate
+// boxes (see Gate in layout.hpp).
+RT_FN bool hit_box_reference(const Real* b, const TravRay<Real>& r) {
+	const Real kMax = std::is_same<Real, float>::value ? Real(3.402823466e+38) : Real(1.7976931348623157e+308);
+	const Real o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
+	bool ok = true;
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+		Real t0 = (b[a] - o[a]) * inv[a];
+		Real t1 = (b[3 + a] - o[a]) * inv[a];
+		if (inv[a] < Real(0)) { Real s = t0; t0 = t1; t1 = s; }
+		Real mn = t0 > Real(0.001) ? t0 : Real(0.001);
+		Real mx = t1 < kMax ? t1 : kMax;
+		ok = ok && !(mx <= mn);
+	}
+	return ok;
+}
+
+// ---------------------------------------------------------------------------------------
+// Traversal state of one lane.  The stack is an LDS array indexed [entry][thread].
+// Candidates compare by (t, rank): the reference keeps the first object of a leaf among
+// equal t (src/scene.rs:105) and the right child among equal t (src/bvh.rs:98-104); `rank`
+// encodes that order so the result does not depend on the visiting order.
+// ---------------------------------------------------------------------------------------
+template <typename Real> struct Trav {
+	int32_t cur;   // >= 0 inner node, < 0 leaf code, kDone when finished
+	int32_t sp;
+	Real best_t;
+	int32_t best_prim;  // index into prims, -1 = none
+	int32_t best_rank;
+};
+RT_FN void trav_begin(Trav<Real>& tv, const TravRay<Real>& r, const Gate<Real>* gates, int32_t root_gate) {
+	tv.cur = 0; tv.sp = 0; tv.best_t = Fp<Real>::inf(); tv.best_prim = -1; tv.best_rank = -1;
+	if (root_gate >= 0 && !hit_box_reference<Real>(gates[root_gate].box, r)) tv.cur = kDone;
+}
+struct Tally { uint32_t box, sphere, cube; };
+
+// Descends inner nodes until the lane reaches a leaf or runs out of work.
+template <typename Real, bool kCount>
+__device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, const Gate<Real>* gates, int* stack, Tally& tally) {
+	while (tv.cur >= 0) {
+		const Node<Real>& n = nodes[tv.cur];
+		Real el, er;
+		bool hl = hit_box<Real>(n.box, r, tv.best_t, &el);
+		bool hr = hit_box<Real>(n.box + 6, r, tv.best_t, &er);
+		int32_t cl = n.child[0], cr = n.child[1];
+		int32_t gl = n.gate[0], gr = n.gate[1];
+		if (hl && gl >= 0) hl = hit_box_reference<Real>(gates[gl].box, r);
+		if (hr && gr >= 0) hr = hit_box_reference<Real>(gates[gr].box, r);
+		if (kCount) tally.box += 2;
+		if (hl && hr) {
+			bool right_first = er < el;  // nearer child first, the left one on equal entry
+			stack[tv.sp * kBlock] = right_first ? cl : cr;
+			tv.sp++;
+			tv.cur = right_first ? cr : cl;
+		} else if (hl) {
+			tv.cur = cl;
+		} else if (hr) {
+			tv.cur = cr;
+		} else if (tv.sp > 0) {
+			tv.sp--;
+			tv.cur = stack[tv.sp * kBlock];
+		} else {
+			tv.cur = kDone;
+		}
+	}
+}
+// Tests the primitives of the leaf in tv.cur, then pops.
+template <typename Real, bool kCount>
+__device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, int* stack, Tally& tally) {
+	uint32_t code = ~(uint32_t)tv.cur;
+	int32_t first = (int32_t)(code >> 6);
+	int32_t ns = (int32_t)((code >> 3) & 7u), nc = (int32_t)(code & 7u);
+	for (int32_t i = first; i < first + ns; i++) {
+		const Prim<Real>& p = prims[i];
+		Real t;
+		if (kCount) tally.sphere++;
+		if (hit_sphere<Real>(p, r, &t) && t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && p.rank > tv.best_rank))) {
+			tv.best_t = t; tv.best_prim = i; tv.best_rank = p.rank;
+		}
+	}
+	for (int32_t i = first + ns; i < first + ns + nc; i++) {
+		const Prim<Real>& p = prims[i];
+		Real t;
+		if (kCount) tally.cube++;
+		if (hit_cube<Real>(p, r, &t) && t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && p.rank > tv.best_rank))) {
+			tv.best_t = t; tv.best_prim = i; tv.best_rank = p.rank;
+		}
+	}
+	if (tv.sp > 0) {
+		tv.sp--;
+		tv.cur = stack[tv.sp * kBlock];
+	} else {
+		tv.cur = kDone;
+	}
+}
+
+// BVH::trace, src/bvh.rs:130-142, with get_normal of src/shapes/sphere.rs:60-62 and
+// src/shapes/cube.rs:54-64 (Rust signum: +1 for +0.0, -1 for -0.0).
+template <typename Real> struct Hit {
+	V3<Real> p, n;
+	bool front;
+	int32_t id;        // object id
+	int32_t material;  // RTHIP_LAMBERTIAN | RTHIP_METAL | RTHIP_DIELECTRIC
+};
+RT_FN Hit<Real> make_hit(const Prim<Real>& pr, bool is_sphere, const TravRay<Real>& r, Real t) {
+	Hit<Real> h;
+	h.p = r.o + r.d * t;
+	if (is_sphere) {
+		if constexpr (std::is_same<Real, float>::value) h.n = (h.p - ld3(pr.v)) * Fp<float>::rcp(pr.v[3]);
+		else h.n = (h.p - ld3(pr.v)) / pr.v[3];
+	} else {
+		V3<Real> centre;
+		if constexpr (std::is_same<Real, float>::value) centre = (ld3(pr.v) + ld3(pr.v + 3)) * 0.5f;
+		else centre = ld3(pr.v);
+		V3<Real> rel = h.p - centre;
+		Real ax = Fp<Real>::fabs(rel.x), ay = Fp<Real>::fabs(rel.y), az = Fp<Real>::fabs(rel.z);
+		Real maxc = Fp<Real>::fmax(Fp<Real>::fmax(ax, ay), az);
+		if (maxc == ax) h.n = mk<Real>(Fp<Real>::copysign(Real(1), rel.x), Real(0), Real(0));
+		else if (maxc == ay) h.n = mk<Real>(Real(0), Fp<Real>::copysign(Real(1), rel.y), Real(0));
+		else h.n = mk<Real>(Real(0), Real(0), Fp<Real>::copysign(Real(1), rel.z));
+	}
+	h.front = dot(r.d, h.n) < Real(0);
+	if (!h.front) h.n = -h.n;
+	h.id = pr.id & ((1 << kMatShift) - 1);
+	h.material = (pr.id >> kMatShift) & 3;
+	return h;
+}
+
+// Material::reflectance, src/materials.rs:80-85 (Schlick); (1-cos)^5 as a multiply chain.
+RT_FN Real reflectance(Real cosine, Real ref_idx) {
+	Real r0 = (Real(1) - ref_idx) / (Real(1) + ref_idx);
+	r0 = r0 * r0;
+	Real x = Real(1) - cosine;
+	Real x2 = x * x;
+	return r0 + (Real(1) - r0) * ((x2 * x2) * x);
+}
+// Material::scatter, src/materials.rs:17-68.  Returns false for None (an absorbed metal ray).
+// Draw counts: Lambertian 3, Metal 3 (also when fuzz is 0), Dielectric 1 unless total
+// internal reflection (the `||` of :54-55 short-circuits).
+RT_FN bool scatter(const Hit<Real>& h, const Mat<Real>& m, V3<Real> dir_in, Rng& rng, V3<Real>* att, V3<Real>* dir_out) {
+	if (h.material == RTHIP_LAMBERTIAN) {
+		V3<Real> sd = h.n + random_unit_vector<Real>(rng);
+		const Real tol = Real(0.00000001);
+		if (Fp<Real>::fabs(sd.x) <= tol && Fp<Real>::fabs(sd.y) <= tol && Fp<Real>::fabs(sd.z) <= tol) sd = h.n;
+		*att = ld3(m.albedo);
+		*dir_out = sd;
+		return true;
+	}
+	if (h.material == RTHIP_METAL) {
+		V3<Real> reflected = reflect(normalize(dir_in), h.n);
+		V3<Real> sd = reflected + m.param * random_unit_vector<Real>(rng);
+		if (dot(sd, h.n) <= Real(0)) return false;
+		*att = ld3(m.albedo);
+		*dir_out = sd;
+		return true;
+	}
+	Real ir = m.param;
+	Real ratio = h.front ? Fp<Real>::rcp(ir) : ir;
+	V3<Real> unit_dir = normalize(dir_in);
+	Real cos_theta = Fp<Real>::fmin(dot(-unit_dir, h.n), Real(1));
+	Real sin_theta = Fp<Real>::sqrt(Real(1) - (cos_theta * cos_theta));
+	bool cannot_refract = ratio * sin_theta > Real(1);
+	if (cannot_refract || (reflectance<Real>(cos_theta, ratio) > random_range<Real>(Real(0), Real(1), rng))) {
+		*dir_out = reflect(unit_dir, h.n);
+	} else {
+		*dir_out = refract(unit_dir, h.n, ratio);
+	}
+	*att = mk<Real>(Real(1), Real(1), Real(1));
+	return true;
+}
+
+// sqrt(radiance) -> fixed point (2^-36 units).  NaN and negatives count as 0; one sample is
+// capped at 256 (radiance 65536), far above anything a display shows, so sums cannot wrap
+// below 2^20 samples per pixel.
+RT_FN unsigned long long to_fixed(Real v) {
+	double x = (double)v;
+	if (!(x > 0.0)) return 0ull;
+	if (x > 256.0) x = 256.0;
+	return (unsigned long long)(x * kAccumScale + 0.5);
+}
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+enum : int { kIdle = 0, kTraverse = 1, kShade = 2 };
+
+// ---------------------------------------------------------------------------------------
+// The megakernel.
+// ---------------------------------------------------------------------------------------
+template <typename Real, bool kLds, bool kCount>
+__global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs<Real> A) {
+	extern __shared__ __align__(64) char smem[];
+	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kBlock]
+	const uint32_t stack_bytes = (uint32_t)A.stack_entries * kBlock * 4u;
+	const Node<Real>* nodes;
+	const Prim<Real>* prims;
+	const Mat<Real>* mats;
+	const Gate<Real>* gates;
+	if constexpr (kLds) {
+		char* dst = smem + stack_bytes;
+		const uint4* src = reinterpret_cast<const uint4*>(A.scene);
+		for (uint32_t i = threadIdx.x; i < A.scene_bytes / 16u; i += kBlock) reinterpret_cast<uint4*>(dst)[i] = src[i];
+		__syncthreads();
+		nodes = reinterpret_cast<const Node<Real>*>(dst);
+		prims = reinterpret_cast<const Prim<Real>*>(dst + A.prims_off);
+		mats = reinterpret_cast<const Mat<Real>*>(dst + A.mats_off);
+		gates = reinterpret_cast<const Gate<Real>*>(dst + A.gates_off);
+	} else {
+		nodes = reinterpret_cast<const Node<Real>*>(A.scene);
+		prims = reinterpret_cast<const Prim<Real>*>(A.scene + A.prims_off);
+		mats = reinterpret_cast<const Mat<Real>*>(A.scene + A.mats_off);
+		gates = reinterpret_cast<const Gate<Real>*>(A.scene + A.gates_off);
+	}
+	const uint32_t lane = threadIdx.x & 63u;
+
+	// lane state
+	int state = kIdle;
+	TravRay<Real> ray;
+	Trav<Real> tv;
+	V3<Real> T, L;
+	int32_t depth = 0;
+	Rng rng;
+	uint32_t accum_index = 0, sample_slot = 0;
+	Tally tally{0, 0, 0};
+	uint32_t n_rays = 0, n_paths = 0;
+	tv.cur = kDone; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1; tv.best_rank = -1;
+	rng.state = 0; rng.inc = 1;
+	T = L = mk<Real>(0, 0, 0);
+	ray.o = ray.d = ray.inv = T; ray.a = ray.rcp_a = 0;
+
+	// wave state (uniform)
+	uint32_t item = 0, pool_pos = 0, pool_end = 0;
+	bool queue_dry = false;
+	const uint32_t pool_size = 64u * A.chunk;
+
+	for (;;) {
+		// ---- regeneration: hand idle lanes the next paths of the wave's pool -------------
+		for (;;) {
+			unsigned long long need = __ballot(state == kIdle);
+			if (need == 0ull) break;
+			if (pool_pos == pool_end) {
+				if (queue_dry) break;
+				uint32_t it = 0;
+				if (lane == 0) it = atomicAdd(A.queue, 1u);
+				it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+				if (it >= A.n_items) { queue_dry = true; break; }
+				item = it; pool_pos = 0; pool_end = pool_size;
+			}
+			uint32_t want = (uint32_t)__popcll(need);
+			uint32_t avail = pool_end - pool_pos;
+			uint32_t take = want < avail ? want : avail;
+			if (state == kIdle) {
+				uint32_t rk = lane_rank(need);
+				if (rk < take) {
+					uint32_t j = pool_pos + rk;
+					uint32_t tile_local = item / A.n_chunks, chunk_i = item - tile_local * A.n_chunks;
+					uint32_t tile = (uint32_t)A.part_index + tile_local * (uint32_t)A.part_count;
+					uint32_t ty = tile / (uint32_t)A.tiles_x, tx = tile - ty * (uint32_t)A.tiles_x;
+					uint32_t px = tx * kTile + (j & 7u), py = ty * kTile + ((j >> 3) & 7u);
+					uint32_t s_local = chunk_i * A.chunk + (j >> 6);
+					if (px < (uint32_t)A.width && py < (uint32_t)A.height && s_local < A.spp_count) {
+						uint32_t pixel = py * (uint32_t)A.width + px;
+						rng.init(A.seed, pixel, A.spp_begin + s_local);
+						RayT<Real> r = camera_ray<Real>(A.cam, (Real)px, (Real)py, rng, true);
+						accum_index = tile * kTilePixels + (j & 63u);
+						sample_slot = (s_local * (uint32_t)A.height + py) * (uint32_t)A.width + px;
+						T = mk<Real>(1, 1, 1);
+						L = mk<Real>(0, 0, 0);
+						depth = A.max_depth;
+						n_paths++;
+						if (depth > 0) {
+							ray = prepare<Real>(r);
+							trav_begin<Real>(tv, ray, gates, A.root_gate);
+							state = kTraverse;
+						} else if (A.samples_out) {  // renderer.rs:10-12: depth <= 0 -> black
+							Real* so = A.samples_out + (size_t)sample_slot * 3;
+							so[0] = so[1] = so[2] = Real(0);
+						}
+					}
+				}
+			}
+			pool_pos += take;
+		}
+		if (__ballot(state != kIdle) == 0ull) break;
+
+		// ---- traversal: until few lanes are left traversing while others wait -------------
+		for (;;) {
+			unsigned long long m = __ballot(state == kTraverse);
+			if (m == 0ull) break;
+			uint32_t n_trav = (uint32_t)__popcll(m);
+			if ((int32_t)n_trav <= A.trav_threshold) {
+				unsigned long long waiting = __ballot(state == kShade || (state == kIdle && !queue_dry));
+				if (waiting != 0ull) break;
+			}
+			if (state == kTraverse) {
+				trav_inner<Real, kCount>(tv, ray, nodes, gates, stack, tally);
+				if (tv.cur != kDone) trav_leaf<Real, kCount>(tv, ray, prims, stack, tally);
+				if (tv.cur == kDone) state = kShade;
+			}
+		}
+
+		// ---- shading ---------------------------------------------------------------------
+		if (state == kShade) {
+			n_rays++;
+			bool finished = false;
+			if (tv.best_prim < 0) {
+				// renderer.rs:24: sky * contribution, unwound through the attenuations again
+				L = L + T * (sky<Real>(ray.d, A.sky_mode) * T);
+				finished = true;
+			} else {
+				const Prim<Real>& pr = prims[tv.best_prim];
+				bool is_sphere = ((pr.id >> kKindShift) & 1) == RTHIP_SPHERE;
+				Hit<Real> h = make_hit<Real>(pr, is_sphere, ray, tv.best_t);
+				const Mat<Real>& mat = mats[h.id];
+				V3<Real> att, nd;
+				if (!scatter<Real>(h, mat, ray.d, rng, &att, &nd)) {
+					finished = true;  // renderer.rs:20-22: absorbed, this hit's emission is dropped
+				} else {
+					if (h.material == RTHIP_LAMBERTIAN) L = L + T * (ld3(mat.albedo) * mat.param);  // materials.rs:71-77
+					T = T * att;
+					depth--;
+					if (depth <= 0) {
+						finished = true;  // renderer.rs:10-12
+					} else {
+						ray = prepare<Real>(RayT<Real>{h.p, nd});
+						trav_begin<Real>(tv, ray, gates, A.root_gate);
+						state = kTraverse;
+					}
+				}
+			}
+			if (finished) {
+				if (A.samples_out) {
+					Real* so = A.samples_out + (size_t)sample_slot * 3;
+					so[0] = L.x; so[1] = L.y; so[2] = L.z;
+				}
+				// raytracer_headless/src/main.rs:53: gamma (sqrt) per sample, then summed
+				unsigned long long* acc = A.accum + (size_t)accum_index * kAccumChannels;
+				atomicAdd(acc + 0, to_fixed<Real>(Fp<Real>::sqrt(L.x)));
+				atomicAdd(acc + 1, to_fixed<Real>(Fp<Real>::sqrt(L.y)));
+				atomicAdd(acc + 2, to_fixed<Real>(Fp<Real>::sqrt(L.z)));
+				state = kIdle;
+			}
+		}
+	}
+
+	// ---- statistics: one atomic per wave ------------------------------------------------
+	unsigned long long v[5] = {n_paths, n_rays, tally.box, tally.sphere, tally.cube};
+	const int nstat = kCount ? 5 : 2;
+	for (int k = 0; k < nstat; k++) {
+		unsigned long long s = v[k];
+		for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+		if (lane == 0) atomicAdd(A.stats + k, s);
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// Parity probe: one primary ray per pixel, hit record written out.
+// ---------------------------------------------------------------------------------------
+template <typename Real>
+__global__ __launch_bounds__(kBlock) void probe_kernel(ProbeArgs<Real> A) {
+	extern __shared__ __align__(64) char smem[];
+	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
+	const Node<Real>* nodes = reinterpret_cast<const Node<Real>*>(A.scene);
+	const Prim<Real>* prims = reinterpret_cast<const Prim<Real>*>(A.scene + A.prims_off);
+	const Gate<Real>* gates = reinterpret_cast<const Gate<Real>*>(A.scene + A.gates_off);
+	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= (uint32_t)A.width * (uint32_t)A.height) return;
+	uint32_t py = i / (uint32_t)A.width, px = i - py * (uint32_t)A.width;
+	Rng rng;
+	rng.init(A.seed, i, A.sample);
+	TravRay<Real> ray = prepare<Real>(camera_ray<Real>(A.cam, (Real)px, (Real)py, rng, A.jitter != 0));
+	Trav<Real> tv;
+	trav_begin<Real>(tv, ray, gates, A.root_gate);
+	Tally tally{0, 0, 0};
+	while (tv.cur != kDone) {
+		trav_inner<Real, false>(tv, ray, nodes, gates, stack, tally);
+		if (tv.cur != kDone) trav_leaf<Real, false>(tv, ray, prims, stack, tally);
+	}
+	if (tv.best_prim < 0) {
+		A.id[i] = -1; A.t[i] = 0.0; A.front[i] = 0;
+		A.normal[3 * (size_t)i] = A.normal[3 * (size_t)i + 1] = A.normal[3 * (size_t)i + 2] = 0.0;
+		return;
+	}
+	const Prim<Real>& pr = prims[tv.best_prim];
+	Hit<Real> h = make_hit<Real>(pr, ((pr.id >> kKindShift) & 1) == RTHIP_SPHERE, ray, tv.best_t);
+	A.id[i] = h.id; A.t[i] = (double)tv.best_t; A.front[i] = h.front ? 1 : 0;
+	A.normal[3 * (size_t)i] = (double)h.n.x; A.normal[3 * (size_t)i + 1] = (double)h.n.y; A.normal[3 * (size_t)i + 2] = (double)h.n.z;
+}
+
+#undef RT_FN
+}  // namespace rthip

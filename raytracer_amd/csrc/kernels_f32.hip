@@ -1,0 +1,50 @@
+// kernels_f32.hip — production instantiation: f32 VALU arithmetic, fp contraction allowed.
+#include "launch.hpp"
+#define RT_REAL float
+#include "kernels_impl.inc"
+
+namespace rthip {
+
+__device__ __forceinline__ size_t accum_offset(uint32_t x, uint32_t y, int tiles_x) {
+	uint32_t tile = (y / kTile) * (uint32_t)tiles_x + (x / kTile);
+	return ((size_t)tile * kTilePixels + (y % kTile) * kTile + (x % kTile)) * kAccumChannels;
+}
+__global__ void unpack_accum_kernel(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (uint32_t)width * (uint32_t)height) return;
+	size_t src = accum_offset(i % (uint32_t)width, i / (uint32_t)width, tiles_x);
+	for (int c = 0; c < 3; c++) rgb[(size_t)i * 3 + c] = (double)accum[src + c] * (1.0 / kAccumScale);
+}
+// `(v * 255.0) as u8` of Rust: truncation toward zero, saturating, NaN -> 0.
+__device__ __forceinline__ uint32_t quantize(unsigned long long fixed, double spp) {
+	double v = ((double)fixed * (1.0 / kAccumScale)) / spp * 255.0;
+	if (!(v > 0.0)) return 0u;
+	if (v >= 255.0) return 255u;
+	return (uint32_t)v;
+}
+__global__ void finalize_kernel(const unsigned long long* accum, void* out, int width, int height, int tiles_x, unsigned spp, int xrgb) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (uint32_t)width * (uint32_t)height) return;
+	size_t src = accum_offset(i % (uint32_t)width, i / (uint32_t)width, tiles_x);
+	uint32_t r = quantize(accum[src], (double)spp), g = quantize(accum[src + 1], (double)spp), b = quantize(accum[src + 2], (double)spp);
+	if (xrgb) {
+		static_cast<uint32_t*>(out)[i] = (r << 16) | (g << 8) | b;
+	} else {
+		uint8_t* o = static_cast<uint8_t*>(out) + (size_t)i * 3;
+		o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
+	}
+}
+hipError_t launch_finalize(const unsigned long long* accum, void* out, int width, int height, int tiles_x, unsigned spp, int xrgb, hipStream_t s) {
+	unsigned n = (unsigned)width * (unsigned)height;
+	hipLaunchKernelGGL(finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, accum, out, width, height, tiles_x, spp, xrgb);
+	return hipGetLastError();
+}
+
+hipError_t render_blocks_per_cu_f32(bool scene_in_lds, size_t dyn_lds, int* blocks) { return blocks_per_cu_impl(scene_in_lds, dyn_lds, blocks); }
+
+hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x, hipStream_t s) {
+	unsigned n = (unsigned)width * (unsigned)height;
+	hipLaunchKernelGGL(unpack_accum_kernel, dim3((n + 255) / 256), dim3(256), 0, s, accum, rgb, width, height, tiles_x);
+	return hipGetLastError();
+}
+}  // namespace rthip

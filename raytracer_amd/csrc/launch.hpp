@@ -1,0 +1,30 @@
+// launch.hpp — host-callable launchers, one set per arithmetic type (each defined in its own
+// translation unit so that f64 can be built with -ffp-contract=off and f32 without).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace rthip {
+
+struct LaunchCfg {
+	int grid;            // workgroups
+	size_t dyn_lds;      // bytes of dynamic LDS
+	bool scene_in_lds;
+	bool count;          // instrumented (box / sphere / cube test counters)
+};
+
+hipError_t launch_render(const RenderArgs<float>& a, const LaunchCfg& cfg, hipStream_t s);
+hipError_t launch_render(const RenderArgs<double>& a, const LaunchCfg& cfg, hipStream_t s);
+hipError_t launch_probe(const ProbeArgs<float>& a, size_t dyn_lds, hipStream_t s);
+hipError_t launch_probe(const ProbeArgs<double>& a, size_t dyn_lds, hipStream_t s);
+// Resident workgroups per CU for the render kernel at this much dynamic LDS.
+hipError_t render_blocks_per_cu_f32(bool scene_in_lds, size_t dyn_lds, int* blocks);
+hipError_t render_blocks_per_cu_f64(bool scene_in_lds, size_t dyn_lds, int* blocks);
+// Accumulation buffer (tile-major fixed point) -> row-major [H][W][3] doubles (sums).
+hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x, hipStream_t s);
+// raytracer_headless/src/main.rs:6-12,55: (accum / spp * 255.0) as u8.  xrgb = 0: RGB8 bytes
+// [H][W][3]; xrgb = 1: one 0x00RRGGBB word per pixel (raytracer_runtime/src/main.rs:15-17).
+hipError_t launch_finalize(const unsigned long long* accum, void* out, int width, int height, int tiles_x, unsigned spp, int xrgb, hipStream_t s);
+
+}  // namespace rthip

@@ -1,0 +1,76 @@
+// layout.hpp — the scene as it lies in HBM (and, for small scenes, in LDS).
+//
+// The tree is binary and reference-shaped (median split, leaves of 1..5 objects), but it is
+// stored "children in the parent": an inner node holds the boxes of BOTH children, so one
+// 64-byte fetch (f32) decides where a ray goes next and leaves are never fetched as nodes.
+// Primitives are stored in leaf order, 32 bytes each (f32), spheres before cubes inside a
+// leaf so that the leaf loop has no per-primitive type branch.  Materials are indexed by
+// object id and fetched once per ray, at shading time.
+#pragma once
+#include <cstdint>
+
+#include "../../include/rthip.h"
+
+namespace rthip {
+
+constexpr int kTile = 8;              // tiles are 8x8 pixels = one wave of primary rays
+constexpr int kTilePixels = 64;
+constexpr int kStackMax = 24;         // per-lane traversal stack entries (tree depth limit)
+constexpr int kAccumChannels = 4;     // r, g, b, unused: 32 bytes per pixel
+constexpr double kAccumScale = 68719476736.0;  // 2^36 fixed-point units per 1.0
+constexpr int kMatShift = 28;         // Prim::id = object id | material type << 28 | kind << 30
+constexpr int kKindShift = 30;
+constexpr int kMaxObjects = 1 << 25;  // leaf code holds the first primitive in 25 bits
+
+// child >= 0: index of an inner node.  child < 0: leaf, ~child = first_prim << 6 | n_spheres << 3 | n_cubes.
+constexpr int32_t leaf_code(int32_t first, int32_t ns, int32_t nc) { return ~((first << 6) | (ns << 3) | nc); }
+
+template <typename Real>
+struct alignas(sizeof(Real) * 16) Node {
+	Real box[12];      // left child lo.xyz hi.xyz, right child lo.xyz hi.xyz
+	int32_t child[2];  // left, right
+	int32_t gate[2];   // per child: index of its gate box, or -1 (see Gate)
+};
+static_assert(sizeof(Node<float>) == 64, "f32 node is one 64-byte line");
+static_assert(sizeof(Node<double>) == 128, "f64 node is 128 bytes");
+
+// Sphere: v = centre.xyz, radius, 0, 0.
+// Cube, f64: v = centre.xyz, half_extent.xyz (the reference's own representation).
+// Cube, f32: v = lo.xyz, hi.xyz, computed in f64 as centre -/+ half_extent and rounded once,
+//            so that huge cubes (ground slabs of half extent 1e5) keep exact faces.
+template <typename Real>
+struct alignas(sizeof(Real) * 8) Prim {
+	Real v[6];
+	int32_t id;    // object id | material type << kMatShift | kind << kKindShift
+	int32_t rank;  // tie rank: among equal t the larger rank wins
+};
+static_assert(sizeof(Prim<float>) == 32, "f32 primitive is 32 bytes");
+static_assert(sizeof(Prim<double>) == 64, "f64 primitive is 64 bytes");
+
+// Gate box.  BVH::new (src/bvh.rs:53-56,68) unions the boxes objects cache, and a sphere of
+// negative radius caches an INVERTED box (src/shapes/sphere.rs:13-19) that adds nothing to a
+// union.  Where a split separates such an inner sphere from the outer shell that would have
+// covered it, the reference's box for the subtree is smaller than the subtree's true bounds,
+// and the reference reaches the inner sphere only for rays that pass its per-axis test
+// (src/math.rs:356-371) on that smaller box.  To return the same hits, a child whose
+// reference box differs from its true bounds carries that reference box as a gate: the ray
+// must pass the reference's test on it as well.  Everywhere else that test is implied by the
+// slab test and no gate is stored.
+template <typename Real>
+struct Gate {
+	Real box[6];  // lo.xyz hi.xyz as the reference computes them
+};
+
+template <typename Real>
+struct alignas(sizeof(Real) * 4) Mat {
+	Real albedo[3];
+	Real param;  // Lambertian: emission ; Metal: fuzz ; Dielectric: ir
+};
+
+template <typename Real>
+struct CameraT {  // src/camera.rs:4-12
+	Real origin[3], pixel00[3], delta_x[3], delta_y[3], disk_x[3], disk_y[3];
+	Real defocus_angle;
+};
+
+}  // namespace rthip
