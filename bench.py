@@ -1,0 +1,222 @@
+"""Benchmark of the path-tracing hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torch.distributed.run)
+
+A step = one pass of the hot path: render `spp` samples of every pixel of the workload's frame
+into the accumulation buffer resident in HBM (and, for N > 1, merge the ranks' buffers with one
+RCCL reduce).  Scaling is weak: every GPU renders its own `spp` samples of the full frame, so
+N GPUs deliver an image of N x spp samples in the same time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import raytracer_amd as rt  # noqa: E402
+from raytracer_amd import distributed as D  # noqa: E402
+
+SCENE_SEED = 0x5EED0001
+RENDER_SEED = 0x5EED0001
+HEADLESS_CAMERA = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)  # raytracer_headless/src/main.rs:20-28
+PEAK_FP32_VALU_TFLOPS = 157.3
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the headless default scene at 1080p, 100 spp, depth 10
+    "cfg2": dict(scene="default", width=1920, height=1080, spp=100, depth=10,
+                 desc="configs[1]: Scene::create_sample_scene (seed 0x5EED0001), headless camera, 1920x1080, 100 spp, depth 10"),
+    # BASELINE.json configs[2]: many spheres and cubes, 1080p, 500 spp, depth 50
+    "cfg3": dict(scene="sample", width=1920, height=1080, spp=500, depth=50,
+                 desc="configs[2]: scenes::create_sample_scene (many spheres and cubes, seed 0x5EED0001), headless camera, 1920x1080, 500 spp, depth 50"),
+}
+
+
+def host_threads():
+    for var in ("OMP_NUM_THREADS",):
+        v = os.environ.get(var)
+        if v and v.isdigit() and int(v) > 0:
+            return int(v)
+    return os.cpu_count() or 1
+
+
+def cpu_side(scene, wl, run_baseline):
+    """Oracle legs (rank 0, N = 1 only): algorithmic work per path from a TIGHT-mode count on a
+    reduced frame of the same view, and the reference algorithm (FAITHFUL) timed on a bounded
+    sample of the workload."""
+    from oracle import binding as ob  # measurement only: never on the product path
+    osc = ob.OracleScene(scene.objects)
+    cam_small = ob.camera_desc(*HEADLESS_CAMERA, wl["width"] // 8, wl["height"] // 8)
+    _, _, cnt, _ = osc.render(cam_small, 4, wl["depth"], RENDER_SEED, ob.TIGHT, threads=host_threads())
+    work = dict(flop_per_path=ob.algorithmic_flops(cnt) / cnt["paths"], bytes_per_path=ob.algorithmic_bytes(cnt) / cnt["paths"],
+                rays_per_path=cnt["rays"] / cnt["paths"], box_tests_per_ray=cnt["box_tests"] / cnt["rays"],
+                prim_tests_per_ray=(cnt["sphere_tests"] + cnt["cube_tests"]) / cnt["rays"])
+    baseline = None
+    if run_baseline:
+        threads = host_threads()
+        cam_full = ob.camera_desc(*HEADLESS_CAMERA, wl["width"], wl["height"])
+        # size the sample to ~15 s of CPU work from a quick probe: whole frames when they are
+        # cheap enough (spp >= 1), else a centred band of rows at 1 spp
+        _, _, c0, s0 = osc.render(cam_small, 2, wl["depth"], RENDER_SEED, ob.FAITHFUL, threads=threads)
+        budget_paths = 15.0 * c0["paths"] / s0
+        frame = wl["width"] * wl["height"]
+        if budget_paths >= frame:
+            spp, rows, y0 = int(min(wl["spp"], budget_paths // frame)), wl["height"], 0
+        else:
+            spp, rows = 1, int(max(8, budget_paths // wl["width"]))
+            y0 = (wl["height"] - rows) // 2
+        _, _, c1, s1 = osc.render(cam_full, spp, wl["depth"], RENDER_SEED, ob.FAITHFUL, threads=threads,
+                                  window=(0, y0, wl["width"], y0 + rows))
+        baseline = dict(value=c1["paths"] / s1 / 1e6, unit="Mpaths/s", cores=threads, kind="port",
+                        sample=f"rows {y0}..{y0 + rows} of the {wl['width']}x{wl['height']} frame, {spp} spp, depth {wl['depth']}: "
+                               f"{c1['paths']} paths in {s1:.1f} s; f64 restatement of the reference algorithm "
+                               f"(recursive both-children BVH walk, per-axis AABB test), row-parallel on {threads} threads",
+                        mrays_per_s=c1["rays"] / s1 / 1e6)
+    return work, baseline
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per GPU per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 / 1-spp frame extras")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    def run_workload(name, steps, warmup, spp_override=0):
+        wl = dict(WORKLOADS[name])
+        if spp_override:
+            wl["spp"] = spp_override
+        scene = rt.Scene.generate(wl["scene"], SCENE_SEED)
+        cam = rt.Camera(*HEADLESS_CAMERA, wl["width"], wl["height"])
+        r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED)
+        stream = torch.cuda.current_stream(device)
+        r.set_stream(stream.cuda_stream)
+        accum = D.new_accum_tensor(wl["width"], wl["height"], device)
+        r.set_accum_buffer(accum.data_ptr(), accum.numel())
+        begin = rank * wl["spp"]  # weak scaling: every rank renders its own samples of the full frame
+
+        def step():
+            accum.zero_()
+            r.accumulate(wl["spp"], spp_begin=begin, sync=False)
+            D.merge_accum(accum, dst=0)
+
+        for _ in range(warmup):
+            step()
+        kernel_ms = []
+        rays = paths = 0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            if rank == 0:
+                s = r.stats()  # waits for this step's kernel (HIP events on the launch stream)
+                kernel_ms.append(s["kernel_ms"]); rays, paths = s["rays"], s["paths"]
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        out = dict(wl=wl, scene=scene, elapsed=elapsed, kernel_ms=float(np.mean(kernel_ms)) if kernel_ms else 0.0,
+                   rays=rays, paths=paths, stats=r.stats() if rank == 0 else None)
+        # the 1-spp progressive frame (raytracer_runtime-style caller): ms per frame
+        if rank == 0 and name == "cfg2" and not args.no_extra and world == 1:
+            r.reset_accumulation()
+            for _ in range(3):
+                r.accumulate(1)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                r.accumulate(1, sync=False)
+            r.synchronize()
+            out["frame_ms_1spp"] = (time.perf_counter() - t1) / 20 * 1e3
+        r.close()
+        return out
+
+    res = run_workload(args.workload, args.steps, args.warmup, args.spp)
+    wl = res["wl"]
+    paths_per_step_all = wl["width"] * wl["height"] * wl["spp"] * world
+    value = paths_per_step_all * args.steps / res["elapsed"] / 1e6
+
+    if rank == 0:
+        line = {
+            "metric": "Mpaths/s (path-tracing throughput, 1080p)", "value": value, "unit": "Mpaths/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["elapsed"] / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "spp_per_gpu_per_step": wl["spp"], "split": "spp (each GPU renders its own samples of the full frame; one RCCL reduce merges)",
+                       "scene_objects": int(len(res["scene"])), "tree_depth": res["stats"]["tree_depth"], "scene_in_lds": res["stats"]["scene_in_lds"]},
+            "mrays_per_s": res["rays"] * world * args.steps / res["elapsed"] / 1e6 if res["kernel_ms"] else None,
+            "rays_per_path": res["rays"] / max(1, res["paths"]),
+        }
+        if "frame_ms_1spp" in res:
+            line["frame_ms_1080p_1spp"] = res["frame_ms_1spp"]
+        work, baseline = (None, None)
+        if world == 1:
+            work, baseline = cpu_side(res["scene"], wl, not args.no_cpu)
+        if work:
+            flops_per_launch = work["flop_per_path"] * res["paths"]
+            achieved = flops_per_launch / (res["kernel_ms"] * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(args.workload)
+            line["roofline"] = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                                "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "kernel": "render_kernel<float>",
+                                "kernel_ms": res["kernel_ms"], "algorithmic_flop_per_path": work["flop_per_path"],
+                                "algorithmic_bytes_per_path": work["bytes_per_path"], "box_tests_per_ray": work["box_tests_per_ray"],
+                                "prim_tests_per_ray": work["prim_tests_per_ray"]}
+        if baseline:
+            line["cpu_baseline"] = baseline
+            line["speedup_vs_cpu"] = value / baseline["value"]
+        if world == 1 and not args.no_extra and args.workload == "cfg2":
+            # the many-spheres-and-cubes target workload, measured in the same run
+            r3 = run_workload("cfg3", 2, 1)
+            w3 = r3["wl"]
+            v3 = w3["width"] * w3["height"] * w3["spp"] * 2 / r3["elapsed"] / 1e6
+            extra = {"workload": w3["desc"], "value": v3, "unit": "Mpaths/s", "ms_per_step": r3["elapsed"] / 2 * 1e3,
+                     "mrays_per_s": r3["rays"] * 2 / r3["elapsed"] / 1e6, "kernel_ms": r3["kernel_ms"]}
+            if not args.no_cpu:
+                work3, base3 = cpu_side(r3["scene"], w3, True)
+                ach3 = work3["flop_per_path"] * r3["paths"] / (r3["kernel_ms"] * 1e-3) / 1e12
+                extra.update(cpu_baseline=base3, speedup_vs_cpu=v3 / base3["value"],
+                             roofline={"bound": "valu_fp32", "achieved": ach3, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": ach3 / PEAK_FP32_VALU_TFLOPS, "algorithmic_flop_per_path": work3["flop_per_path"]})
+            line["cfg3"] = extra
+        print(json.dumps(line))
+    elif world == 1:
+        pass
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,8 +83,17 @@ def lib():
         L.oracle_emission.argtypes = [C.c_int32, _D3, C.c_double, _D3]
         L.oracle_rng_words.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p]
         L.oracle_camera_ray.argtypes = [C.POINTER(CameraDesc), C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32, _D3, _D3]
+        L.oracle_camera_rays.argtypes = [C.POINTER(CameraDesc), C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
+
+
+def camera_rays(cam, seed, sample, jitter):
+    """(origins, dirs), each [H, W, 3]: the primary rays of sample `sample`."""
+    o = np.zeros((cam.height, cam.width, 3), np.float64)
+    d = np.zeros((cam.height, cam.width, 3), np.float64)
+    lib().oracle_camera_rays(C.byref(cam), seed, sample, int(jitter), o.ctypes.data, d.ctypes.data)
+    return o, d
 
 
 def d3(v):

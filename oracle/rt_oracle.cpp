@@ -955,4 +955,19 @@ void oracle_camera_ray(const oracle_camera_desc* cd, int32_t x, int32_t y, uint3
 	dir[0] = r.dir.x; dir[1] = r.dir.y; dir[2] = r.dir.z;
 }
 
+// The rays get_ray() returns for sample `sample` of every pixel, row-major [H][W][3].
+void oracle_camera_rays(const oracle_camera_desc* cd, uint32_t seed, uint32_t sample, int32_t jitter, double* origins, double* dirs) {
+	Camera cam = camera_from_desc(cd);
+	for (int y = 0; y < cd->height; y++) {
+		for (int x = 0; x < cd->width; x++) {
+			size_t i = (size_t)y * cd->width + x;
+			PathRng rng;
+			rng.init(seed, (uint32_t)i, sample);
+			Ray r = camera_get_ray(cam, (Scalar)x, (Scalar)y, rng, jitter != 0);
+			origins[3 * i] = r.origin.x; origins[3 * i + 1] = r.origin.y; origins[3 * i + 2] = r.origin.z;
+			dirs[3 * i] = r.dir.x; dirs[3 * i + 1] = r.dir.y; dirs[3 * i + 2] = r.dir.z;
+		}
+	}
+}
+
 }  // extern "C"

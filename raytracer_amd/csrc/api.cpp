@@ -120,14 +120,25 @@ int32_t validate(rthip_ctx* c, const rthip_render_params* p) {
 int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* plan) {
 	const bool f64 = p->precision == RTHIP_F64;
 	const SceneBlob& blob = f64 ? c->blob64 : c->blob32;
-	size_t stack_bytes = (size_t)c->tree_depth * kBlock * 4;
 	int lds_mode = env_int("RTHIP_SCENE_LDS", -1);
-	bool in_lds = lds_mode < 0 ? blob.bytes <= kLdsSceneLimit : (lds_mode != 0 && blob.bytes + stack_bytes <= 150 * 1024);
+	bool in_lds = lds_mode < 0 ? blob.bytes <= kLdsSceneLimit : (lds_mode != 0 && blob.bytes <= 100 * 1024);
 	plan->cfg.scene_in_lds = in_lds;
 	plan->cfg.count = count;
-	plan->cfg.dyn_lds = stack_bytes + (in_lds ? blob.bytes : 0);
-	int bpc = 0;
-	HIP_TRY(c, f64 ? render_blocks_per_cu_f64(in_lds, plan->cfg.dyn_lds, &bpc) : render_blocks_per_cu_f32(in_lds, plan->cfg.dyn_lds, &bpc));
+	// Workgroup size: the kernel is latency bound, so pick the size that keeps the most waves
+	// resident.  Every workgroup holds its own LDS copy of the scene, so larger workgroups
+	// amortise it.
+	int forced = env_int("RTHIP_THREADS", 0);
+	int best_waves = -1, bpc = 0;
+	for (int threads : {256, 512}) {
+		if (forced && threads != forced) continue;
+		size_t lds = (size_t)c->tree_depth * threads * 4 + (in_lds ? blob.bytes : 0);
+		int b = 0;
+		HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, in_lds, lds, &b) : render_blocks_per_cu_f32(threads, in_lds, lds, &b));
+		if (b * threads / 64 > best_waves) {
+			best_waves = b * threads / 64; bpc = b;
+			plan->cfg.threads = threads; plan->cfg.dyn_lds = lds;
+		}
+	}
 	if (bpc < 1) return fail(c, RTHIP_ERR_LIMIT, "render kernel does not fit on a CU");
 	int cap = env_int("RTHIP_BLOCKS_PER_CU", 0);
 	if (cap > 0) bpc = std::min(bpc, cap);
@@ -139,7 +150,8 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	uint64_t n_items = my_tiles * n_chunks;
 	if (n_items > 0xFFFFFF00ull) return fail(c, RTHIP_ERR_LIMIT, "too many work items in one call: lower spp_count");
 	plan->chunk = chunk; plan->n_chunks = n_chunks; plan->n_items = (uint32_t)n_items;
-	uint64_t want_blocks = (n_items + 3) / 4;
+	uint64_t waves_per_block = (uint64_t)plan->cfg.threads / 64;
+	uint64_t want_blocks = (n_items + waves_per_block - 1) / waves_per_block;
 	plan->cfg.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc * c->num_cu, want_blocks));
 	plan->threshold = env_int("RTHIP_TRAV_THRESHOLD", 24);
 	return RTHIP_OK;
@@ -418,7 +430,7 @@ int32_t rthip_trace_primary(rthip_ctx* c, int32_t precision, int32_t jitter, uin
 	char* d = nullptr;
 	size_t off_t = align_up(n * 4, 64), off_n = off_t + align_up(n * 8, 64), off_f = off_n + align_up(n * 24, 64), total = off_f + align_up(n, 64);
 	HIP_TRY(c, hipMalloc(&d, total));
-	size_t lds = (size_t)c->tree_depth * kBlock * 4;
+	size_t lds = (size_t)c->tree_depth * kProbeBlock * 4;
 	hipError_t e;
 	if (precision == RTHIP_F64) {
 		ProbeArgs<double> a;

@@ -35,7 +35,7 @@
 
 namespace rthip {
 
-constexpr int kBlock = 256;
+constexpr int kProbeBlock = 256;  // threads per workgroup of the parity probe
 constexpr int kDone = INT32_MIN;  // traversal finished (not a valid leaf code)
 
 template <typename Real>
@@ -345,7 +345,7 @@ RT_FN void trav_begin(Trav<Real>& tv, const TravRay<Real>& r, const Gate<Real>* 
 struct Tally { uint32_t box, sphere, cube; };
 
 // Descends inner nodes until the lane reaches a leaf or runs out of work.
-template <typename Real, bool kCount>
+template <typename Real, int kThreads, bool kCount>
 __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, const Gate<Real>* gates, int* stack, Tally& tally) {
 	while (tv.cur >= 0) {
 		const Node<Real>& n = nodes[tv.cur];
@@ -359,7 +359,7 @@ __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& 
 		if (kCount) tally.box += 2;
 		if (hl && hr) {
 			bool right_first = er < el;  // nearer child first, the left one on equal entry
-			stack[tv.sp * kBlock] = right_first ? cl : cr;
+			stack[tv.sp * kThreads] = right_first ? cl : cr;
 			tv.sp++;
 			tv.cur = right_first ? cr : cl;
 		} else if (hl) {
@@ -368,14 +368,14 @@ __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& 
 			tv.cur = cr;
 		} else if (tv.sp > 0) {
 			tv.sp--;
-			tv.cur = stack[tv.sp * kBlock];
+			tv.cur = stack[tv.sp * kThreads];
 		} else {
 			tv.cur = kDone;
 		}
 	}
 }
 // Tests the primitives of the leaf in tv.cur, then pops.
-template <typename Real, bool kCount>
+template <typename Real, int kThreads, bool kCount>
 __device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, int* stack, Tally& tally) {
 	uint32_t code = ~(uint32_t)tv.cur;
 	int32_t first = (int32_t)(code >> 6);
@@ -398,7 +398,7 @@ __device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r
 	}
 	if (tv.sp > 0) {
 		tv.sp--;
-		tv.cur = stack[tv.sp * kBlock];
+		tv.cur = stack[tv.sp * kThreads];
 	} else {
 		tv.cur = kDone;
 	}
@@ -498,11 +498,11 @@ enum : int { kIdle = 0, kTraverse = 1, kShade = 2 };
 // ---------------------------------------------------------------------------------------
 // The megakernel.
 // ---------------------------------------------------------------------------------------
-template <typename Real, bool kLds, bool kCount>
-__global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs<Real> A) {
+template <typename Real, int kThreads, bool kLds, bool kCount>
+__global__ __launch_bounds__(kThreads) void render_kernel(RenderArgs<Real> A) {
 	extern __shared__ __align__(64) char smem[];
-	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kBlock]
-	const uint32_t stack_bytes = (uint32_t)A.stack_entries * kBlock * 4u;
+	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kThreads]
+	const uint32_t stack_bytes = (uint32_t)A.stack_entries * kThreads * 4u;
 	const Node<Real>* nodes;
 	const Prim<Real>* prims;
 	const Mat<Real>* mats;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs<Real> A) {
 	if constexpr (kLds) {
 		char* dst = smem + stack_bytes;
 		const uint4* src = reinterpret_cast<const uint4*>(A.scene);
-		for (uint32_t i = threadIdx.x; i < A.scene_bytes / 16u; i += kBlock) reinterpret_cast<uint4*>(dst)[i] = src[i];
+		for (uint32_t i = threadIdx.x; i < A.scene_bytes / 16u; i += kThreads) reinterpret_cast<uint4*>(dst)[i] = src[i];
 		__syncthreads();
 		nodes = reinterpret_cast<const Node<Real>*>(dst);
 		prims = reinterpret_cast<const Prim<Real>*>(dst + A.prims_off);
@@ -604,8 +604,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs<Real> A) {
 				if (waiting != 0ull) break;
 			}
 			if (state == kTraverse) {
-				trav_inner<Real, kCount>(tv, ray, nodes, gates, stack, tally);
-				if (tv.cur != kDone) trav_leaf<Real, kCount>(tv, ray, prims, stack, tally);
+				trav_inner<Real, kThreads, kCount>(tv, ray, nodes, gates, stack, tally);
+				if (tv.cur != kDone) trav_leaf<Real, kThreads, kCount>(tv, ray, prims, stack, tally);
 				if (tv.cur == kDone) state = kShade;
 			}
 		}
@@ -668,13 +668,13 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs<Real> A) {
 // Parity probe: one primary ray per pixel, hit record written out.
 // ---------------------------------------------------------------------------------------
 template <typename Real>
-__global__ __launch_bounds__(kBlock) void probe_kernel(ProbeArgs<Real> A) {
+__global__ __launch_bounds__(kProbeBlock) void probe_kernel(ProbeArgs<Real> A) {
 	extern __shared__ __align__(64) char smem[];
 	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
 	const Node<Real>* nodes = reinterpret_cast<const Node<Real>*>(A.scene);
 	const Prim<Real>* prims = reinterpret_cast<const Prim<Real>*>(A.scene + A.prims_off);
 	const Gate<Real>* gates = reinterpret_cast<const Gate<Real>*>(A.scene + A.gates_off);
-	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	uint32_t i = blockIdx.x * kProbeBlock + threadIdx.x;
 	if (i >= (uint32_t)A.width * (uint32_t)A.height) return;
 	uint32_t py = i / (uint32_t)A.width, px = i - py * (uint32_t)A.width;
 	Rng rng;
@@ -684,8 +684,8 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(ProbeArgs<Real> A) {
 	trav_begin<Real>(tv, ray, gates, A.root_gate);
 	Tally tally{0, 0, 0};
 	while (tv.cur != kDone) {
-		trav_inner<Real, false>(tv, ray, nodes, gates, stack, tally);
-		if (tv.cur != kDone) trav_leaf<Real, false>(tv, ray, prims, stack, tally);
+		trav_inner<Real, kProbeBlock, false>(tv, ray, nodes, gates, stack, tally);
+		if (tv.cur != kDone) trav_leaf<Real, kProbeBlock, false>(tv, ray, prims, stack, tally);
 	}
 	if (tv.best_prim < 0) {
 		A.id[i] = -1; A.t[i] = 0.0; A.front[i] = 0;

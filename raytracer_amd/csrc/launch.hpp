@@ -9,6 +9,7 @@ namespace rthip {
 
 struct LaunchCfg {
 	int grid;            // workgroups
+	int threads;         // threads per workgroup: 256 or 512
 	size_t dyn_lds;      // bytes of dynamic LDS
 	bool scene_in_lds;
 	bool count;          // instrumented (box / sphere / cube test counters)
@@ -19,8 +20,8 @@ hipError_t launch_render(const RenderArgs<double>& a, const LaunchCfg& cfg, hipS
 hipError_t launch_probe(const ProbeArgs<float>& a, size_t dyn_lds, hipStream_t s);
 hipError_t launch_probe(const ProbeArgs<double>& a, size_t dyn_lds, hipStream_t s);
 // Resident workgroups per CU for the render kernel at this much dynamic LDS.
-hipError_t render_blocks_per_cu_f32(bool scene_in_lds, size_t dyn_lds, int* blocks);
-hipError_t render_blocks_per_cu_f64(bool scene_in_lds, size_t dyn_lds, int* blocks);
+hipError_t render_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks);
+hipError_t render_blocks_per_cu_f64(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks);
 // Accumulation buffer (tile-major fixed point) -> row-major [H][W][3] doubles (sums).
 hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x, hipStream_t s);
 // raytracer_headless/src/main.rs:6-12,55: (accum / spp * 255.0) as u8.  xrgb = 0: RGB8 bytes

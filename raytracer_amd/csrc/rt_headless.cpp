@@ -1,0 +1,180 @@
+// rt_headless — C++ counterpart of raytracer_headless/src/main.rs:14-73 over the C ABI:
+// the host program a maintainer gets by adding `--backend hip` to the reference's headless
+// binary.  Same defaults (2560x1440, depth 10, 800 spp, the default scene, the same camera),
+// same output (RGB8 PNG, `(v * 255.0) as u8`), same "Rendering took {}s" line; the frame loop
+// is one library call instead of the rayon loop.
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rthip.h"
+
+namespace {
+
+// ---- minimal PNG writer (RGB8, stored deflate blocks) ------------------------------------
+uint32_t crc_table[256];
+void crc_init() {
+	for (uint32_t n = 0; n < 256; n++) {
+		uint32_t c = n;
+		for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+		crc_table[n] = c;
+	}
+}
+uint32_t crc_update(uint32_t c, const uint8_t* p, size_t n) {
+	for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+	return c;
+}
+void put32(std::vector<uint8_t>& v, uint32_t x) {
+	v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+void chunk(std::vector<uint8_t>& out, const char tag[4], const std::vector<uint8_t>& data) {
+	put32(out, (uint32_t)data.size());
+	size_t start = out.size();
+	out.insert(out.end(), tag, tag + 4);
+	out.insert(out.end(), data.begin(), data.end());
+	put32(out, crc_update(0xFFFFFFFFu, out.data() + start, out.size() - start) ^ 0xFFFFFFFFu);
+}
+bool write_png(const std::string& path, const uint8_t* rgb, int w, int h) {
+	crc_init();
+	std::vector<uint8_t> raw;
+	raw.reserve((size_t)h * ((size_t)w * 3 + 1));
+	for (int y = 0; y < h; y++) {
+		raw.push_back(0);  // filter: none
+		raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3);
+	}
+	std::vector<uint8_t> z = {0x78, 0x01};
+	uint32_t a = 1, b = 0;
+	for (uint8_t v : raw) { a = (a + v) % 65521u; b = (b + a) % 65521u; }
+	for (size_t pos = 0; pos < raw.size();) {
+		size_t n = std::min<size_t>(65535, raw.size() - pos);
+		z.push_back(pos + n == raw.size() ? 1 : 0);
+		z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+		z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+		z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+		pos += n;
+	}
+	put32(z, (b << 16) | a);
+	std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+	std::vector<uint8_t> ihdr;
+	put32(ihdr, (uint32_t)w); put32(ihdr, (uint32_t)h);
+	ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+	chunk(out, "IHDR", ihdr);
+	chunk(out, "IDAT", z);
+	chunk(out, "IEND", {});
+	FILE* f = std::fopen(path.c_str(), "wb");
+	if (!f) return false;
+	bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+	std::fclose(f);
+	return ok;
+}
+
+int usage() {
+	std::fprintf(stderr,
+	             "usage: rt_headless --backend hip [--scene default|sample|simple|glass|metal|wallpaper|synthetic:N]\n"
+	             "       [--width W] [--height H] [--spp N] [--max-depth D] [--seed S] [--scene-seed S] [--precision f32|f64]\n"
+	             "       [--sky reference|wallpaper] [--device I] [--chunk-spp N] [--out output.png]\n");
+	return 2;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+	// raytracer_headless/src/main.rs:15-18
+	int width = 2560, height = 1440, max_depth = 10, device = 0;
+	uint32_t samples = 800, seed = 0x5EED0001u, scene_seed = 0x5EED0001u, chunk_spp = 100;
+	std::string backend = "hip", scene = "default", out = "output.png", precision = "f32", sky = "reference";
+	for (int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : nullptr; };
+		const char* v = nullptr;
+		if (a == "--backend" && (v = next())) backend = v;
+		else if (a == "--scene" && (v = next())) scene = v;
+		else if (a == "--width" && (v = next())) width = std::atoi(v);
+		else if (a == "--height" && (v = next())) height = std::atoi(v);
+		else if (a == "--spp" && (v = next())) samples = (uint32_t)std::strtoul(v, nullptr, 0);
+		else if (a == "--max-depth" && (v = next())) max_depth = std::atoi(v);
+		else if (a == "--seed" && (v = next())) seed = (uint32_t)std::strtoul(v, nullptr, 0);
+		else if (a == "--scene-seed" && (v = next())) scene_seed = (uint32_t)std::strtoul(v, nullptr, 0);
+		else if (a == "--precision" && (v = next())) precision = v;
+		else if (a == "--sky" && (v = next())) sky = v;
+		else if (a == "--device" && (v = next())) device = std::atoi(v);
+		else if (a == "--chunk-spp" && (v = next())) chunk_spp = (uint32_t)std::strtoul(v, nullptr, 0);
+		else if (a == "--out" && (v = next())) out = v;
+		else return usage();
+	}
+	if (backend != "hip") {
+		std::fprintf(stderr, "rt_headless: only --backend hip is built here; the CPU backend is the reference's own raytracer_headless\n");
+		return 2;
+	}
+	if (samples == 0 || width < 1 || height < 1 || chunk_spp == 0) return usage();
+
+	int64_t n = 0;
+	if (rthip_scene_generate(scene.c_str(), scene_seed, nullptr, 0, &n) != RTHIP_OK) {
+		std::fprintf(stderr, "rt_headless: %s\n", rthip_last_error(nullptr));
+		return 1;
+	}
+	std::vector<rthip_object> objects((size_t)n);
+	rthip_scene_generate(scene.c_str(), scene_seed, objects.data(), n, &n);
+
+	rthip_ctx* ctx = nullptr;
+	if (rthip_create(device, &ctx) != RTHIP_OK) {
+		std::fprintf(stderr, "rt_headless: %s\n", rthip_last_error(nullptr));
+		return 1;
+	}
+	auto die = [&](const char* what) {
+		std::fprintf(stderr, "rt_headless: %s: %s\n", what, rthip_last_error(ctx));
+		rthip_destroy(ctx);
+		return 1;
+	};
+	// raytracer_headless/src/main.rs:20-30
+	rthip_camera_desc cam;
+	std::memset(&cam, 0, sizeof(cam));
+	if (scene == "wallpaper") {  // raytracer_gpu/src/main.rs:70: origin, yaw -90, fov 90
+		rthip_camera_rotation(-90.0, 0.0, cam.direction);
+		cam.fov = 90.0;
+	} else {
+		cam.origin[0] = 13.0; cam.origin[1] = 1.5; cam.origin[2] = 3.0;
+		double len = std::sqrt(13.0 * 13.0 + 1.5 * 1.5 + 3.0 * 3.0);
+		cam.direction[0] = -(13.0 / len); cam.direction[1] = -(1.5 / len); cam.direction[2] = -(3.0 / len);
+		cam.fov = 20.0;
+	}
+	cam.focus_dist = 10.0; cam.defocus_angle = 0.6; cam.width = width; cam.height = height;
+	if (rthip_scene_upload(ctx, objects.data(), n) != RTHIP_OK) return die("scene");
+	if (rthip_camera_set(ctx, &cam) != RTHIP_OK) return die("camera");
+
+	auto start = std::chrono::steady_clock::now();  // main.rs:32
+	rthip_render_params p;
+	std::memset(&p, 0, sizeof(p));
+	p.max_depth = max_depth; p.seed = seed; p.part_count = 1;
+	p.precision = precision == "f64" ? RTHIP_F64 : RTHIP_F32;
+	p.sky_mode = sky == "wallpaper" ? RTHIP_SKY_WALLPAPER : RTHIP_SKY_REFERENCE;
+	uint64_t rays = 0;
+	double kernel_ms = 0;
+	for (uint32_t done = 0; done < samples; done += chunk_spp) {  // main.rs:43: the sample loop, in launches of chunk_spp
+		p.spp_begin = done;
+		p.spp_count = std::min(chunk_spp, samples - done);
+		if (rthip_render_accumulate(ctx, &p) != RTHIP_OK) return die("render");
+		rthip_stats s;
+		rthip_get_stats(ctx, &s);
+		rays += s.rays; kernel_ms += s.kernel_ms;
+	}
+	double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+	std::printf("Rendering took %gs\n", secs);  // main.rs:59-62
+	double paths = (double)width * height * samples;
+	std::printf("%.1f Mpaths/s, %.1f Mrays/s (kernel time %.3f s), %lld objects\n", paths / secs / 1e6, (double)rays / secs / 1e6,
+	            kernel_ms / 1e3, (long long)n);
+
+	std::vector<uint8_t> rgb((size_t)width * height * 3);
+	if (rthip_read_rgb8(ctx, samples, rgb.data()) != RTHIP_OK) return die("readback");  // main.rs:55,64-69
+	rthip_destroy(ctx);
+	if (!write_png(out, rgb.data(), width, height)) {  // main.rs:70-72
+		std::fprintf(stderr, "failed to save to %s\n", out.c_str());
+		return 1;
+	}
+	return 0;
+}

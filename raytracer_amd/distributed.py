@@ -1,0 +1,54 @@
+"""Multi-GPU partitioning and merge for the path tracer: one process per GPU.
+
+Every (pixel, sample) is independent (the random stream is keyed by seed, pixel and sample)
+and the scene is replicated, so a render shards two ways with no exchange during tracing:
+
+* spp split: rank r renders samples [r * spp / N, (r + 1) * spp / N) of every pixel;
+* tile split: rank r renders the 8x8 tiles t with t % N == r.
+
+Either way each rank ends with a full-frame accumulation buffer of 64-bit integers (zeros
+where it owns nothing) and the image is their element-wise sum: ONE reduce over RCCL/xGMI.
+Integer sums commute, so the merged image is bit-identical to a single-GPU render.
+There is no counterpart in the reference, which is a single-process renderer.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def spp_slice(spp_total, rank, world):
+    """Contiguous sample range of `rank`: (begin, count)."""
+    lo = spp_total * rank // world
+    hi = spp_total * (rank + 1) // world
+    return lo, hi - lo
+
+
+def tile_part(rank, world):
+    """(part_index, part_count) for rthip_render_params."""
+    return rank, world
+
+
+def accum_words(width, height):
+    return ((width + 7) // 8) * ((height + 7) // 8) * 64 * 4
+
+
+def new_accum_tensor(width, height, device):
+    """A zeroed accumulation buffer as an int64 tensor (uint64 words of 2^-36; sums stay far
+    below 2^63, so int64 addition is exact)."""
+    return torch.zeros(accum_words(width, height), dtype=torch.int64, device=device)
+
+
+def merge_accum(accum, dst=0, group=None):
+    """Sum every rank's accumulation buffer into rank `dst` (a single reduce)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return accum
+
+
+def accum_to_image(accum, width, height):
+    """Decode a (merged) accumulation buffer to sum_s sqrt(sample), float64 [H, W, 3], on the host."""
+    words = accum.detach().cpu().numpy().view(np.uint64)
+    tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
+    a = words.reshape(tiles_y, tiles_x, 8, 8, 4)
+    img = a.transpose(0, 2, 1, 3, 4).reshape(tiles_y * 8, tiles_x * 8, 4)[:height, :width, :3]
+    return img.astype(np.float64) / 2.0 ** 36

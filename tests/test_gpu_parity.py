@@ -1,0 +1,269 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the
+golden vectors.  Bars: f64 arithmetic bit-exact (hit ids, t, normals, per-sample radiance);
+f32 (production) hit ids equal except at silhouettes, t and normals within the stated
+relative tolerance, images within the stated RMSE."""
+import os
+
+import numpy as np
+import pytest
+
+from util import SCENES, camera_args
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# f32 (production) tolerances, stated here.  The f64 path meets "t and normal within 1e-5" literally
+# (it is bit-exact).  In f32 the primary ray itself is rounded (direction to ~1e-7), and the
+# distance to a surface seen at grazing incidence amplifies that by 1 / |cos(incidence)| (a ray
+# skimming the ground slab toward the horizon has |cos| ~ 1e-4), which no f32 formulation can
+# avoid.  So t is held to 1e-5 relative scaled by that conditioning factor, and the median and
+# the 99th percentile are bounded outright.
+F32_T_RTOL, F32_T_P50, F32_T_P99, F32_N_ATOL = 1e-5, 2e-7, 5e-6, 2e-4
+
+
+@pytest.fixture(scope="module")
+def renderers(rt):
+    cache = {}
+
+    def get(scene, w, h, **kw):
+        key = (scene, w, h, tuple(sorted(kw.items())))
+        if key not in cache:
+            sc = rt.Scene.generate(scene)
+            cache[key] = (rt.Renderer(sc, rt.Camera(*camera_args(scene.split(":")[0] if ":" not in scene else "default", w, h, rt)), **kw), sc)
+        return cache[key]
+
+    yield get
+    for r, _ in cache.values():
+        r.close()
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_f64_probe_bit_exact_vs_golden_and_oracle(rt, oracle, renderers, scene):
+    g = np.load(os.path.join(GOLD, f"{scene}.npz"))
+    w, h = int(g["width"]), int(g["height"])
+    r, sc = renderers(scene, w, h, seed=int(g["seed"]))
+    for jit in (0, 1):
+        ids, t, n, f = r.trace_primary(rt.F64, jitter=bool(jit), sample=int(g["probe_sample"]))
+        assert np.array_equal(ids, g[f"id{jit}"]), "primary-hit object ids differ"
+        assert np.array_equal(t, g[f"t{jit}"]) and np.array_equal(n, g[f"n{jit}"]) and np.array_equal(f, g[f"front{jit}"])
+    # a larger frame against the oracle run here
+    r2, _ = renderers(scene, 320, 180, seed=5)
+    osc = oracle.OracleScene(sc.objects)
+    cam = oracle.camera_desc(*camera_args(scene, 320, 180, rt))
+    for jit in (False, True):
+        ref = osc.trace_primary(cam, oracle.TIGHT, jitter=jit, seed=5, sample=9)
+        got = r2.trace_primary(rt.F64, jitter=jit, sample=9)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_f32_probe_within_tolerance(rt, oracle, renderers, scene):
+    r, sc = renderers(scene, 320, 180, seed=5)
+    osc = oracle.OracleScene(sc.objects)
+    cam = oracle.camera_desc(*camera_args(scene, 320, 180, rt))
+    for jit in (False, True):
+        rid, rtt, rn, rf = osc.trace_primary(cam, oracle.TIGHT, jitter=jit, seed=5, sample=9)
+        gid, gt, gn, gf = r.trace_primary(rt.F32, jitter=jit, sample=9)
+        _, dirs = oracle.camera_rays(cam, 5, 9, jit)
+        mismatch = rid != gid
+        assert mismatch.mean() <= 2e-4, f"{mismatch.sum()} primary-hit ids differ"   # silhouette pixels only
+        same = (~mismatch) & (rid >= 0)
+        rel = np.abs(gt - rtt)[same] / rtt[same]
+        cos = np.abs((dirs * rn).sum(axis=-1))[same]          # primary directions are unit length
+        assert (rel <= F32_T_RTOL / np.maximum(cos, 1e-6)).all(), float((rel * cos).max())
+        assert np.percentile(rel, 50) <= F32_T_P50 and np.percentile(rel, 99) <= F32_T_P99
+        assert np.abs(gn - rn)[same].max(initial=0) <= F32_N_ATOL
+        assert np.array_equal(gf[same], rf[same])
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_f64_samples_bit_exact(rt, oracle, renderers, scene):
+    """Per-sample radiance of the whole path tracer (camera, traversal, materials, stream)."""
+    g = np.load(os.path.join(GOLD, f"{scene}.npz"))
+    w, h, spp = int(g["width"]), int(g["height"]), int(g["spp"])
+    r, sc = renderers(scene, w, h, seed=int(g["seed"]))
+    r.max_depth, r.sky_mode = int(g["max_depth"]), int(g["sky_mode"])
+    got = r.render_samples(spp, precision=rt.F64)
+    s = r.stats()
+    assert s["rays"] == int(g["rays"]) and s["paths"] == w * h * spp
+    # golden = the reference's recursive form; the kernels use the unrolled form: equal up to
+    # the order of the last multiply-adds.  (The wallpaper sky goes through pow(): 1e-9.)
+    rtol = 1e-9 if int(g["sky_mode"]) == 1 else 1e-12
+    assert np.allclose(got, g["samples"], rtol=rtol, atol=1e-300)
+    if int(g["sky_mode"]) == 0:
+        osc = oracle.OracleScene(sc.objects)
+        cam = oracle.camera_desc(*camera_args(scene, w, h, rt))
+        _, ref, _, _ = osc.render(cam, spp, int(g["max_depth"]), int(g["seed"]), oracle.TIGHT, samples=True)
+        assert np.array_equal(got, ref), "f64 kernel differs from the same algorithm on the CPU"
+    r.max_depth, r.sky_mode = 10, 0
+
+
+@pytest.mark.parametrize("scene", ["default", "sample", "glass"])
+def test_f32_image_rmse(rt, oracle, renderers, scene):
+    """Production precision against the CPU render on the same stream: RMSE of the mean
+    (gamma-space) image <= 2e-3, i.e. about half an 8-bit step; PSNR >= 54 dB."""
+    w, h, spp, depth = 160, 90, 16, 10 if scene != "sample" else 50
+    r, sc = renderers(scene, w, h, seed=21)
+    r.max_depth, r.precision = depth, rt.F32
+    r.reset_accumulation()
+    r.accumulate(spp)
+    img = r.read_accum() / spp
+    osc = oracle.OracleScene(sc.objects)
+    cam = oracle.camera_desc(*camera_args(scene, w, h, rt))
+    ref, _, cnt, _ = osc.render(cam, spp, depth, 21, oracle.TIGHT)
+    ref = ref / spp
+    rmse = float(np.sqrt(((np.clip(img, 0, 1) - np.clip(ref, 0, 1)) ** 2).mean()))
+    assert rmse <= 2e-3, rmse
+    assert abs(r.stats()["rays"] - cnt["rays"]) <= 2e-3 * cnt["rays"]
+    q, qref = r.read_rgb8(spp), oracle.quantize_rgb8(ref)
+    assert (np.abs(q.astype(int) - qref.astype(int)) > 1).mean() <= 2e-3
+    r.max_depth = 10
+
+
+def test_f64_accumulate_and_quantize(rt, oracle, renderers):
+    w, h, spp = 64, 40, 5
+    r, sc = renderers("default", w, h, seed=3)
+    r.precision = rt.F64
+    r.reset_accumulation()
+    r.accumulate(spp)
+    acc = r.read_accum()
+    osc = oracle.OracleScene(sc.objects)
+    ref, _, _, _ = osc.render(oracle.camera_desc(*camera_args("default", w, h, rt)), spp, 10, 3, oracle.TIGHT)
+    assert np.abs(acc - ref).max() <= spp * 2.0 ** -36          # one rounding to 2^-36 per sample
+    assert np.array_equal(r.read_rgb8(spp), oracle.quantize_rgb8(acc / spp))
+    x = r.read_xrgb32(spp)
+    q = r.read_rgb8(spp).astype(np.uint32)
+    assert np.array_equal(x, (q[..., 0] << 16) | (q[..., 1] << 8) | q[..., 2])   # raytracer_runtime/src/main.rs:15-17
+    r.precision = rt.F32
+
+
+@pytest.mark.parametrize("size", [(37, 23), (8, 8), (1, 1), (130, 7)])
+def test_ragged_image_sizes(rt, oracle, size):
+    w, h = size
+    sc = rt.Scene.generate("default")
+    r = rt.Renderer(sc, rt.Camera(*camera_args("default", w, h, rt)), seed=4, precision=rt.F64)
+    got = r.render_samples(3)
+    osc = oracle.OracleScene(sc.objects)
+    _, ref, _, _ = osc.render(oracle.camera_desc(*camera_args("default", w, h, rt)), 3, 10, 4, oracle.TIGHT, samples=True)
+    assert np.array_equal(got, ref)
+    r.accumulate(3)
+    assert r.stats()["paths"] == w * h * 3
+    r.close()
+
+
+def test_partition_and_sample_split_are_bit_identical(rt, renderers):
+    """Size-independent property at the full 1080p frame: any split of tiles or samples over
+    calls gives the same accumulation buffer, bit for bit, and runs are reproducible."""
+    w, h, spp = 1920, 1080, 4
+    r, _ = renderers("default", w, h, seed=8)
+    r.precision = rt.F32
+    r.reset_accumulation(); r.accumulate(spp)
+    whole = r.read_accum()
+    assert r.stats()["paths"] == w * h * spp
+    r.reset_accumulation(); r.accumulate(spp)
+    assert np.array_equal(r.read_accum(), whole)
+    r.reset_accumulation()
+    for part in range(4):
+        r.accumulate(spp, part=(part, 4), spp_begin=0)
+    assert np.array_equal(r.read_accum(), whole)
+    r.reset_accumulation()
+    r.accumulate(1, spp_begin=0); r.accumulate(3, spp_begin=1)
+    assert np.array_equal(r.read_accum(), whole)
+    # additivity: accumulating the same samples twice doubles every word
+    r.accumulate(spp, spp_begin=0)
+    assert np.array_equal(r.read_accum(), 2 * whole)
+    # a different seed is a different image
+    r2_seed = r.seed
+    r.seed = 9
+    r.reset_accumulation(); r.accumulate(spp)
+    assert not np.array_equal(r.read_accum(), whole)
+    r.seed = r2_seed
+
+
+def test_progressive_accumulation_and_reset(rt, renderers):  # raytracer_runtime/src/main.rs:69-94,101-149
+    r, _ = renderers("default", 96, 54, seed=2)
+    r.precision = rt.F32
+    r.reset_accumulation()
+    for _ in range(3):
+        r.accumulate(1)
+    assert r.spp_done == 3
+    a = r.read_accum()
+    r.reset_accumulation(); r.accumulate(3)
+    assert np.array_equal(r.read_accum(), a)
+    r.update_camera(rt.Camera((1.0, 1.5, 3.0), rt.get_camera_rotation(10.0, -5.0), 90.0, 10.0, 0.6, 96, 54))
+    assert r.spp_done == 0 and not r.read_accum().any()
+    r.update_camera(rt.Camera(*camera_args("default", 96, 54, rt)))
+
+
+def test_depth_limits(rt, oracle, renderers):  # renderer.rs:10-12
+    r, sc = renderers("default", 48, 27, seed=6)
+    for depth in (0, 1, 2, 50):
+        r.max_depth = depth
+        got = r.render_samples(2, precision=rt.F64)
+        osc = oracle.OracleScene(sc.objects)
+        _, ref, cnt, _ = osc.render(oracle.camera_desc(*camera_args("default", 48, 27, rt)), 2, depth, 6, oracle.TIGHT, samples=True)
+        assert np.array_equal(got, ref)
+        assert r.stats()["rays"] == cnt["rays"]
+        if depth == 0:
+            assert not got.any()
+    r.max_depth = 10
+
+
+def test_caller_owned_accumulation_buffer(rt, renderers):
+    import torch
+    from raytracer_amd import distributed as D
+    w, h = 64, 40
+    r, _ = renderers("default", w, h, seed=12)
+    r.precision = rt.F32
+    r.reset_accumulation(); r.accumulate(2)
+    own = r.read_accum()
+    buf = D.new_accum_tensor(w, h, "cuda:0")
+    r.set_accum_buffer(buf.data_ptr(), buf.numel())
+    r.accumulate(2, spp_begin=0)
+    torch.cuda.synchronize()
+    assert np.array_equal(D.accum_to_image(buf, w, h), own)
+    r.set_accum_buffer(0, 0)
+
+
+def test_error_statuses(rt):
+    from raytracer_amd import _native as N
+    import ctypes as C
+    lib = N.lib()
+    ctx = C.c_void_p()
+    assert lib.rthip_create(10_000, C.byref(ctx)) == N.ERR_INVALID
+    N.check(lib.rthip_create(0, C.byref(ctx)))
+    p = N.RenderParams(0, 1, 10, 1, 0, 0, 0, 0, 1)
+    assert lib.rthip_render_accumulate(ctx, C.byref(p)) == N.ERR_STATE          # nothing uploaded yet
+    assert lib.rthip_scene_upload(ctx, None, 0) == N.ERR_EMPTY                   # bvh.rs:51
+    assert b"None" in lib.rthip_last_error(ctx)
+    objs = rt.Scene.generate("simple").objects
+    N.check(lib.rthip_scene_upload(ctx, objs.ctypes.data, len(objs)), ctx)
+    cam = rt.Camera(*camera_args("simple", 16, 16, rt))
+    N.check(lib.rthip_camera_set(ctx, C.byref(cam.desc)), ctx)
+    for bad in (N.RenderParams(0, 1, 10, 1, 5, 0, 0, 0, 1), N.RenderParams(0, 1, 10, 1, 0, 3, 0, 0, 1),
+                N.RenderParams(0, 1, 10, 1, 0, 0, 0, 2, 2), N.RenderParams(0, 1, 10, 1, 0, 0, 7, 0, 1)):
+        assert lib.rthip_render_accumulate(ctx, C.byref(bad)) == N.ERR_INVALID
+    N.check(lib.rthip_render_accumulate(ctx, C.byref(p)), ctx)
+    p0 = N.RenderParams(0, 0, 10, 1, 0, 0, 0, 0, 1)                               # zero samples: a no-op
+    N.check(lib.rthip_render_accumulate(ctx, C.byref(p0)), ctx)
+    lib.rthip_destroy(ctx)
+
+
+def test_large_synthetic_scene_f64_vs_oracle(rt, oracle):
+    """A scene too large for LDS (global-memory traversal path), deep tree."""
+    sc = rt.create_synthetic_scene(200_000, seed=2)
+    cam_args = ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0, 96, 54)
+    r = rt.Renderer(sc, rt.Camera(*cam_args), seed=13, precision=rt.F64, max_depth=8)
+    osc = oracle.OracleScene(sc.objects)
+    cam = oracle.camera_desc(*cam_args)
+    ref = osc.trace_primary(cam, oracle.TIGHT, jitter=True, seed=13, sample=1)
+    got = r.trace_primary(rt.F64, jitter=True, sample=1)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    _, smp, cnt, _ = osc.render(cam, 2, 8, 13, oracle.TIGHT, samples=True)
+    got = r.render_samples(2)
+    assert np.array_equal(got, smp) and r.stats()["scene_in_lds"] == 0
+    g32 = r.trace_primary(rt.F32, jitter=True, sample=1)
+    assert (g32[0] != ref[0]).mean() <= 2e-3
+    r.close()

@@ -1,0 +1,18 @@
+"""Short fixed workload for rocprofv3: a few launches of the render kernel on the bench
+workloads (cfg2 by default; pass cfg3 as the first argument)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as rt
+
+CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+launches = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+scene, depth = ("default", 10) if which == "cfg2" else ("sample", 50)
+r = rt.Renderer(rt.Scene.generate(scene), rt.Camera(*CAM, 1920, 1080), max_depth=depth, seed=1)
+for i in range(launches):
+    r.reset_accumulation()
+    r.accumulate(spp, spp_begin=0)
+    s = r.stats()
+    print(f"{which} launch {i}: {s['paths']/s['kernel_ms']/1e3:.1f} Mpaths/s, {s['kernel_ms']:.3f} ms, {s['rays']} rays")
+r.close()
