@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librthip.so")
+LIB_PATH = os.environ.get("RTHIP_LIBRARY") or os.path.join(_HERE, "librthip.so")  # override: A/B builds of the same ABI
 
 OK, ERR_INVALID, ERR_EMPTY, ERR_STATE, ERR_HIP, ERR_LIMIT = 0, 1, 2, 3, 4, 5
 SPHERE, CUBE = 0, 1

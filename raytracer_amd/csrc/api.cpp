@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -33,7 +34,7 @@ struct rthip_ctx {
 
 	bool has_scene = false, has_camera = false;
 	SceneBlob blob32, blob64;
-	int tree_depth = 0, n_nodes = 0, n_leaves = 0, n_prims = 0, root_gate = -1;
+	int tree_depth = 0, n_nodes = 0, n_leaves = 0, n_prims = 0;
 
 	CameraFields cam{};
 	int tiles_x = 0, tiles_y = 0;
@@ -43,7 +44,7 @@ struct rthip_ctx {
 	unsigned long long* accum = nullptr;  // active buffer (own or caller's)
 	uint64_t accum_words = 0;
 
-	char* d_control = nullptr;  // 64 bytes: queue counter at +0, 5 statistics words at +8
+	char* d_control = nullptr;  // 512 bytes: queue counter at +0, statistics words from +8
 	rthip_stats stats{};
 	bool launch_pending = false;
 	bool last_in_lds = false;
@@ -166,7 +167,6 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	RenderArgs<Real> a;
 	std::memset(&a, 0, sizeof(a));
 	a.scene = blob.dev; a.prims_off = blob.prims_off; a.mats_off = blob.mats_off; a.gates_off = blob.gates_off; a.scene_bytes = blob.bytes;
-	a.root_gate = c->root_gate;
 	a.stack_entries = c->tree_depth;
 	fill_camera<Real>(c->cam, &a.cam);
 	a.width = c->cam.width; a.height = c->cam.height; a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y;
@@ -176,7 +176,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.accum = accum; a.samples_out = samples_out;
 	a.queue = reinterpret_cast<uint32_t*>(c->d_control);
 	a.stats = reinterpret_cast<unsigned long long*>(c->d_control + 8);
-	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 64, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 512, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
 	if (plan.n_items > 0 && p->spp_count > 0) HIP_TRY(c, launch_render(a, plan.cfg, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -188,8 +188,17 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 int32_t collect_stats(rthip_ctx* c) {
 	if (!c->launch_pending) return RTHIP_OK;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	unsigned long long s[5];
+	unsigned long long s[5 + 2 * kRegCount];
 	HIP_TRY(c, hipMemcpy(s, c->d_control + 8, sizeof(s), hipMemcpyDeviceToHost));
+	if (const char* dump = std::getenv("RTHIP_REGION_DUMP")) {  // instrumented runs: lane utilisation per code region
+		static const char* names[kRegCount] = {"inner", "sphere", "cube", "leaf", "shade", "sky", "lambert", "metal", "glass", "start", "trav_round"};
+		if (FILE* f = std::fopen(dump, "a")) {
+			for (int k = 0; k < kRegCount; k++)
+				std::fprintf(f, "%s lane_iters %llu wave_iters %llu util %.3f\n", names[k], s[5 + k], s[5 + kRegCount + k],
+				             s[5 + kRegCount + k] ? (double)s[5 + k] / (64.0 * (double)s[5 + kRegCount + k]) : 0.0);
+			std::fclose(f);
+		}
+	}
 	float ms = 0.f;
 	HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->stats.paths = s[0]; c->stats.rays = s[1]; c->stats.box_tests = s[2]; c->stats.sphere_tests = s[3]; c->stats.cube_tests = s[4];
@@ -241,7 +250,7 @@ int32_t rthip_create(int32_t device, rthip_ctx** out) {
 	c->stream = c->own_stream;
 	if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
 	if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-	if ((e = hipMalloc(&c->d_control, 64)) != hipSuccess) return bail("hipMalloc", e);
+	if ((e = hipMalloc(&c->d_control, 512)) != hipSuccess) return bail("hipMalloc", e);
 	*out = c;
 	return RTHIP_OK;
 }
@@ -285,7 +294,6 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 	if (rc != RTHIP_OK) return rc;
 	rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
 	if (rc != RTHIP_OK) return rc;
-	c->root_gate = flat.root_gate;
 	c->tree_depth = flat.depth; c->n_nodes = (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)flat.prims32.size();
 	c->stats.n_nodes = c->n_nodes; c->stats.n_leaves = c->n_leaves; c->stats.n_prims = c->n_prims; c->stats.tree_depth = c->tree_depth;
 	c->has_scene = true;
@@ -436,7 +444,7 @@ int32_t rthip_trace_primary(rthip_ctx* c, int32_t precision, int32_t jitter, uin
 		ProbeArgs<double> a;
 		std::memset(&a, 0, sizeof(a));
 		a.scene = c->blob64.dev; a.prims_off = c->blob64.prims_off; a.mats_off = c->blob64.mats_off; a.gates_off = c->blob64.gates_off;
-		a.scene_bytes = c->blob64.bytes; a.root_gate = c->root_gate;
+		a.scene_bytes = c->blob64.bytes;
 		a.stack_entries = c->tree_depth; fill_camera<double>(c->cam, &a.cam);
 		a.width = c->cam.width; a.height = c->cam.height; a.seed = seed; a.sample = sample; a.jitter = jitter;
 		a.id = reinterpret_cast<int32_t*>(d); a.t = reinterpret_cast<double*>(d + off_t); a.normal = reinterpret_cast<double*>(d + off_n);
@@ -446,7 +454,7 @@ int32_t rthip_trace_primary(rthip_ctx* c, int32_t precision, int32_t jitter, uin
 		ProbeArgs<float> a;
 		std::memset(&a, 0, sizeof(a));
 		a.scene = c->blob32.dev; a.prims_off = c->blob32.prims_off; a.mats_off = c->blob32.mats_off; a.gates_off = c->blob32.gates_off;
-		a.scene_bytes = c->blob32.bytes; a.root_gate = c->root_gate;
+		a.scene_bytes = c->blob32.bytes;
 		a.stack_entries = c->tree_depth; fill_camera<float>(c->cam, &a.cam);
 		a.width = c->cam.width; a.height = c->cam.height; a.seed = seed; a.sample = sample; a.jitter = jitter;
 		a.id = reinterpret_cast<int32_t*>(d); a.t = reinterpret_cast<double*>(d + off_t); a.normal = reinterpret_cast<double*>(d + off_n);
@@ -519,7 +527,7 @@ int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* id
 	if (ids) std::copy(flat.leaf_ids.begin(), flat.leaf_ids.end(), ids);
 	if (leaf_sizes) std::copy(flat.leaf_sizes.begin(), flat.leaf_sizes.end(), leaf_sizes);
 	if (n_leaves) *n_leaves = (int64_t)flat.leaf_sizes.size();
-	if (depth) *depth = flat.depth;
+	if (depth) *depth = flat.ref_depth;
 	return RTHIP_OK;
 }
 

@@ -267,15 +267,46 @@ inline Box box_union(const Box& a, const Box& b) {
 inline float round_down(double v) { float f = (float)v; return ((double)f > v) ? std::nextafterf(f, -INFINITY) : f; }
 inline float round_up(double v) { float f = (float)v; return ((double)f < v) ? std::nextafterf(f, INFINITY) : f; }
 
+inline double box_area(const Box& b) {
+	double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+	if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0;
+	return 2.0 * (dx * dy + dy * dz + dz * dx);
+}
+inline bool box_contains(const Box& outer, const Box& inner) {
+	for (int k = 0; k < 3; k++)
+		if (!(outer.lo[k] <= inner.lo[k] && inner.hi[k] <= outer.hi[k])) return false;
+	return true;
+}
+inline Box empty_box() {
+	Box b;
+	for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
+	return b;
+}
+
+// Two trees are involved.
+//  * The REFERENCE tree (BVH::new, src/bvh.rs:17-81) is built exactly as the reference does.
+//    It is never traversed on the GPU; it fixes what depends on it: the tie rank of every
+//    object, the leaf order reported to callers, and the gate boxes of inverted spheres.
+//  * The DEVICE tree is what the kernels traverse.  A closest hit under the (t, rank) order
+//    does not depend on the shape of the tree that finds it, so the device tree is free to be
+//    a better one: a surface-area-heuristic build over the primitives that can be hit at all
+//    (RTHIP_TREE=sah, the default), or the reference's own shape (RTHIP_TREE=ref).
 struct Builder {
 	const rthip_object* objs;
-	std::vector<int32_t> order;  // object ids, permuted in place by the per-level sorts
+	int64_t n_objs;
+	std::vector<int32_t> order;  // object ids, permuted in place by the reference's per-level sorts
 	FlatScene* out;
 	int max_depth = 0;
+	int max_leaf = 4;
+	double cost_node = 1.0, cost_prim = 0.7;
+
+	struct RefNode { size_t begin, end; int left, right; Box ref; };
+	std::vector<RefNode> ref_nodes;
+	std::vector<int32_t> rank;        // per object id
+	std::vector<uint32_t> gate_word;  // per object id: first gate << 8 | gate count, 0 = none
 
 	// The box the reference caches per object (src/shapes/sphere.rs:19, cube.rs:17): centre
-	// -/+ radius or half extent AS GIVEN, so it is inverted for negative sizes.  Used for the
-	// split axis and the sort key only, exactly as src/bvh.rs:18-43 uses it.
+	// -/+ radius or half extent AS GIVEN, so it is inverted for negative sizes.
 	double ref_min(int32_t id, int axis) const {
 		const rthip_object& o = objs[id];
 		return o.center[axis] - (o.kind == RTHIP_SPHERE ? o.extent[0] : o.extent[axis]);
@@ -283,6 +314,11 @@ struct Builder {
 	double ref_max(int32_t id, int axis) const {
 		const rthip_object& o = objs[id];
 		return o.center[axis] + (o.kind == RTHIP_SPHERE ? o.extent[0] : o.extent[axis]);
+	}
+	Box ref_box(int32_t id) const {
+		Box b;
+		for (int k = 0; k < 3; k++) { b.lo[k] = ref_min(id, k); b.hi[k] = ref_max(id, k); }
+		return b;
 	}
 	// True bounds of the primitive as each precision stores it.
 	Box bounds64(int32_t id) const {
@@ -308,36 +344,19 @@ struct Builder {
 		}
 		return b;
 	}
-
-	// Box of the object as the reference caches it (inverted for negative sizes).
-	Box ref_box(int32_t id) const {
-		Box b;
-		for (int k = 0; k < 3; k++) { b.lo[k] = ref_min(id, k); b.hi[k] = ref_max(id, k); }
-		return b;
+	// A cube with a negative half extent can never be hit (src/shapes/cube.rs:29-37: t1 > t2 on
+	// that axis); it shapes the reference tree but is left out of the device tree.
+	bool can_be_hit(int32_t id) const {
+		const rthip_object& o = objs[id];
+		if (o.kind == RTHIP_SPHERE) return true;
+		return o.extent[0] >= 0.0 && o.extent[1] >= 0.0 && o.extent[2] >= 0.0;
 	}
 
-	struct Sub { int32_t code; Box b64, b32, ref; };
-
-	// Index of a new gate when the reference's box differs from the true bounds, else -1.
-	int32_t gate_for(const Sub& s) {
-		bool same = true;
-		for (int k = 0; k < 3; k++) same = same && s.ref.lo[k] == s.b64.lo[k] && s.ref.hi[k] == s.b64.hi[k];
-		if (same) return -1;
-		Gate<double> g64;
-		Gate<float> g32;
-		for (int k = 0; k < 3; k++) {
-			g64.box[k] = s.ref.lo[k]; g64.box[3 + k] = s.ref.hi[k];
-			g32.box[k] = (float)s.ref.lo[k]; g32.box[3 + k] = (float)s.ref.hi[k];
-		}
-		out->gates64.push_back(g64);
-		out->gates32.push_back(g32);
-		return (int32_t)out->gates64.size() - 1;
-	}
-
-	Sub build(size_t begin, size_t end, int depth) {
+	// ---- reference tree: src/bvh.rs:17-81 ------------------------------------------------
+	int ref_build(size_t begin, size_t end) {
 		size_t len = end - begin;
-		// src/bvh.rs:28-47: the axis of largest extent of the cached boxes; the first such axis
-		// on ties (sort_unstable_by leaves that open; a three-element sort keeps input order).
+		// :28-47: the axis of largest extent of the cached boxes; the first such axis on ties
+		// (sort_unstable_by leaves that open; a three-element sort keeps input order).
 		int axis = 0;
 		double best_range = 0;
 		for (int a = 0; a < 3; a++) {
@@ -349,23 +368,74 @@ struct Builder {
 			double range = bmax - bmin;
 			if (a == 0 || range > best_range) { axis = a; best_range = range; }
 		}
-		// src/bvh.rs:18-26,49: ascending by min+max on that axis.  Equal keys keep their current
-		// order (the reference's unstable sort leaves it unspecified).
+		// :18-26,49: ascending by min+max on that axis.  Equal keys keep their current order
+		// (the reference's unstable sort leaves it unspecified).
 		std::stable_sort(order.begin() + (long)begin, order.begin() + (long)end, [this, axis](int32_t a, int32_t b) {
 			return (ref_min(a, axis) + ref_max(a, axis)) < (ref_min(b, axis) + ref_max(b, axis));
 		});
-		if (len < 6) return emit_leaf(begin, end, depth);  // src/bvh.rs:52-61
-		// src/bvh.rs:62-79: the upper half is the right child.
-		size_t mid = begin + len / 2;
-		int32_t me = (int32_t)out->nodes64.size();
-		out->nodes64.emplace_back();
-		out->nodes32.emplace_back();
-		Sub l = build(begin, mid, depth + 1);
-		Sub r = build(mid, end, depth + 1);
-		write_node(me, l, r);
-		if (depth + 1 > max_depth) max_depth = depth + 1;
-		return Sub{me, box_union(l.b64, r.b64), box_union(l.b32, r.b32), box_union(l.ref, r.ref)};
+		int me = (int)ref_nodes.size();
+		ref_nodes.push_back(RefNode{begin, end, -1, -1, empty_box()});
+		if (len < 6) {  // :52-61
+			Box ref = ref_box(order[begin]);
+			for (size_t i = begin + 1; i < end; i++) ref = box_union(ref, ref_box(order[i]));
+			ref_nodes[(size_t)me].ref = ref;
+			return me;
+		}
+		size_t mid = begin + len / 2;  // :62-79: the upper half is the right child
+		int l = ref_build(begin, mid);
+		int r = ref_build(mid, end);
+		ref_nodes[(size_t)me].left = l;
+		ref_nodes[(size_t)me].right = r;
+		ref_nodes[(size_t)me].ref = box_union(ref_nodes[(size_t)l].ref, ref_nodes[(size_t)r].ref);
+		return me;
 	}
+	// Walks the reference tree left to right: tie ranks (the first object of a leaf wins a tie,
+	// src/scene.rs:105; the right child wins a tie between siblings, src/bvh.rs:98-104, so
+	// leaves rank left to right and objects inside a leaf in reverse), the leaf order, and the
+	// gates: the reference reaches an object only if its per-axis test (src/math.rs:356-371)
+	// passes on the box of every node above it.  For a box that contains the object's true
+	// bounds that is implied by hitting the object; the other boxes become the object's gates.
+	// That happens only to spheres of negative radius, whose own cached box is inverted
+	// (src/shapes/sphere.rs:13-19), below a split that parted them from their outer shell.
+	void ref_annotate(int node, std::vector<int>& chain, int32_t* next_rank) {
+		const RefNode& n = ref_nodes[(size_t)node];
+		chain.push_back(node);
+		if (n.left < 0) {
+			int k = (int)(n.end - n.begin);
+			for (int j = 0; j < k; j++) {
+				int32_t id = order[n.begin + (size_t)j];
+				rank[(size_t)id] = *next_rank + (k - 1 - j);
+				out->leaf_ids.push_back(id);
+				if (objs[id].kind != RTHIP_SPHERE) continue;
+				Box tb = bounds64(id);
+				uint32_t first = (uint32_t)out->gates64.size(), count = 0;
+				for (int anc : chain) {
+					const Box& rb = ref_nodes[(size_t)anc].ref;
+					if (box_contains(rb, tb)) continue;
+					Gate<double> g64;
+					Gate<float> g32;
+					for (int q = 0; q < 3; q++) {
+						g64.box[q] = rb.lo[q]; g64.box[3 + q] = rb.hi[q];
+						g32.box[q] = (float)rb.lo[q]; g32.box[3 + q] = (float)rb.hi[q];
+					}
+					out->gates64.push_back(g64);
+					out->gates32.push_back(g32);
+					count++;
+				}
+				if (count) gate_word[(size_t)id] = (first << 8) | count;
+			}
+			*next_rank += k;
+			out->leaf_sizes.push_back(k);
+			out->n_leaves++;
+		} else {
+			ref_annotate(n.left, chain, next_rank);
+			ref_annotate(n.right, chain, next_rank);
+		}
+		chain.pop_back();
+	}
+
+	// ---- device tree ---------------------------------------------------------------------
+	struct Sub { int32_t code; Box b64, b32; };
 
 	void write_node(int32_t me, const Sub& l, const Sub& r) {
 		Node<double>& n64 = out->nodes64[(size_t)me];
@@ -380,24 +450,22 @@ struct Builder {
 			}
 			n64.child[c] = ch[c]->code;
 			n32.child[c] = ch[c]->code;
-			n64.gate[c] = n32.gate[c] = gate_for(*ch[c]);
 		}
 	}
-
-	Sub emit_leaf(size_t begin, size_t end, int depth) {
-		(void)depth;
-		int k = (int)(end - begin);
+	int32_t new_node() {
+		out->nodes64.emplace_back();
+		out->nodes32.emplace_back();
+		return (int32_t)out->nodes64.size() - 1;
+	}
+	// Appends the primitives ids[0..k) as one leaf: spheres first, then cubes, so the leaf loop
+	// has no per-primitive type branch.
+	Sub emit_leaf(const int32_t* ids, int k) {
 		int32_t first = (int32_t)out->prims64.size();
-		int32_t rank_base = first;  // primitives are appended leaf by leaf, left to right
-		Box b64 = bounds64(order[begin]), b32 = bounds32(order[begin]), ref = ref_box(order[begin]);
+		Box b64 = empty_box(), b32 = empty_box();
 		int ns = 0, nc = 0;
-		// Spheres first, then cubes; the rank keeps the reference's tie rule whatever the
-		// storage order: leaves rank left to right, objects inside a leaf in reverse
-		// (the first object of a leaf wins a tie, src/scene.rs:105; the right child wins a
-		// tie between siblings, src/bvh.rs:98-104).
 		for (int pass = 0; pass < 2; pass++) {
 			for (int j = 0; j < k; j++) {
-				int32_t id = order[begin + (size_t)j];
+				int32_t id = ids[j];
 				const rthip_object& o = objs[id];
 				if ((o.kind == RTHIP_SPHERE) != (pass == 0)) continue;
 				if (pass == 0) ns++; else nc++;
@@ -408,6 +476,9 @@ struct Builder {
 				if (o.kind == RTHIP_SPHERE) {
 					p64.v[3] = o.extent[0];
 					p32.v[3] = (float)o.extent[0];
+					// gate word, carried as a number in the spare slot (exact: < 2^24 in f32 scenes that have gates)
+					p64.v[4] = (double)gate_word[(size_t)id];
+					p32.v[4] = (float)gate_word[(size_t)id];
 				} else {
 					for (int q = 0; q < 3; q++) {
 						p64.v[3 + q] = o.extent[q];
@@ -416,19 +487,138 @@ struct Builder {
 					}
 				}
 				p64.id = p32.id = id | (o.material << kMatShift) | (o.kind << kKindShift);
-				p64.rank = p32.rank = rank_base + (k - 1 - j);
+				p64.rank = p32.rank = rank[(size_t)id];
 				out->prims64.push_back(p64);
 				out->prims32.push_back(p32);
+				b64 = box_union(b64, bounds64(id));
+				b32 = box_union(b32, bounds32(id));
 			}
 		}
-		for (int j = 0; j < k; j++) {
-			int32_t id = order[begin + (size_t)j];
-			out->leaf_ids.push_back(id);
-			if (j > 0) { b64 = box_union(b64, bounds64(id)); b32 = box_union(b32, bounds32(id)); ref = box_union(ref, ref_box(id)); }
+		return Sub{leaf_code(first, ns, nc), b64, b32};
+	}
+
+	// Reference-shaped device tree: the reference's nodes and leaves, minus what cannot be hit.
+	Sub shape_ref(int node, int depth) {
+		const RefNode& n = ref_nodes[(size_t)node];
+		if (n.left < 0) {
+			std::vector<int32_t> ids;
+			for (size_t i = n.begin; i < n.end; i++)
+				if (can_be_hit(order[i])) ids.push_back(order[i]);
+			return emit_leaf(ids.data(), (int)ids.size());
 		}
-		out->leaf_sizes.push_back(k);
-		out->n_leaves++;
-		return Sub{leaf_code(first, ns, nc), b64, b32, ref};
+		int32_t me = new_node();
+		Sub l = shape_ref(n.left, depth + 1);
+		Sub r = shape_ref(n.right, depth + 1);
+		write_node(me, l, r);
+		if (depth + 1 > max_depth) max_depth = depth + 1;
+		return Sub{me, box_union(l.b64, r.b64), box_union(l.b32, r.b32)};
+	}
+
+	// Surface-area-heuristic device tree.
+	struct Item { int32_t id; Box b; double c[3]; };
+	std::vector<Item> items;
+
+	Sub sah_leaf(size_t begin, size_t end) {
+		int32_t ids[8];
+		int k = 0;
+		for (size_t i = begin; i < end; i++) ids[k++] = items[i].id;
+		// inside a leaf keep the reference's order (ascending tie rank reversed = object order is immaterial; sort by id for determinism)
+		std::sort(ids, ids + k);
+		return emit_leaf(ids, k);
+	}
+	Sub sah_build(size_t begin, size_t end, int depth) {
+		size_t n = end - begin;
+		Box bounds = empty_box(), cb = empty_box();
+		for (size_t i = begin; i < end; i++) {
+			bounds = box_union(bounds, items[i].b);
+			for (int k = 0; k < 3; k++) { cb.lo[k] = std::fmin(cb.lo[k], items[i].c[k]); cb.hi[k] = std::fmax(cb.hi[k], items[i].c[k]); }
+		}
+		if (n <= 1) return sah_leaf(begin, end);
+		// keep the recursion within the traversal stack: balanced median splits once a
+		// SAH-shaped subtree could run too deep
+		int levels_left = kStackMax - 1 - depth;
+		int need = 1;
+		while (((size_t)max_leaf << need) < n) need++;
+		bool force_median = need + 1 >= levels_left;
+		double parent_area = box_area(bounds);
+		double best_cost = (n <= (size_t)max_leaf) ? cost_prim * (double)n : INFINITY;
+		int best_axis = -1;
+		double best_pos = 0;
+		size_t best_left = 0;
+		if (!force_median && parent_area > 0) {
+			constexpr int kBins = 32;
+			for (int axis = 0; axis < 3; axis++) {
+				double lo = cb.lo[axis], hi = cb.hi[axis];
+				if (!(hi > lo)) continue;
+				if (n <= 48) {
+					// exact sweep over the sorted centroids
+					std::sort(items.begin() + (long)begin, items.begin() + (long)end, [axis](const Item& a, const Item& b) {
+						return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.id < b.id);
+					});
+					std::vector<double> right_area(n);
+					Box acc = empty_box();
+					for (size_t i = n; i-- > 1;) { acc = box_union(acc, items[begin + i].b); right_area[i] = box_area(acc); }
+					acc = empty_box();
+					for (size_t i = 1; i < n; i++) {
+						acc = box_union(acc, items[begin + i - 1].b);
+						if (items[begin + i].c[axis] == items[begin + i - 1].c[axis]) continue;  // split between distinct centroids only
+						double cost = cost_node + cost_prim * (box_area(acc) * (double)i + right_area[i] * (double)(n - i)) / parent_area;
+						if (cost < best_cost) { best_cost = cost; best_axis = axis; best_pos = 0.5 * (items[begin + i].c[axis] + items[begin + i - 1].c[axis]); best_left = i; }
+					}
+				} else {
+					Box bin_box[kBins];
+					size_t bin_n[kBins];
+					for (int b = 0; b < kBins; b++) { bin_box[b] = empty_box(); bin_n[b] = 0; }
+					double scale = (double)kBins / (hi - lo);
+					for (size_t i = begin; i < end; i++) {
+						int b = (int)((items[i].c[axis] - lo) * scale);
+						b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+						bin_box[b] = box_union(bin_box[b], items[i].b);
+						bin_n[b]++;
+					}
+					double right_area[kBins];
+					size_t right_n[kBins];
+					Box acc = empty_box();
+					size_t cnt = 0;
+					for (int b = kBins - 1; b >= 1; b--) { acc = box_union(acc, bin_box[b]); cnt += bin_n[b]; right_area[b] = box_area(acc); right_n[b] = cnt; }
+					acc = empty_box();
+					cnt = 0;
+					for (int b = 1; b < kBins; b++) {
+						acc = box_union(acc, bin_box[b - 1]);
+						cnt += bin_n[b - 1];
+						if (cnt == 0 || right_n[b] == 0) continue;
+						double cost = cost_node + cost_prim * (box_area(acc) * (double)cnt + right_area[b] * (double)right_n[b]) / parent_area;
+						if (cost < best_cost) { best_cost = cost; best_axis = axis; best_pos = lo + (double)b / scale; best_left = cnt; }
+					}
+				}
+			}
+		}
+		size_t mid;
+		if (best_axis >= 0) {
+			int axis = best_axis;
+			double pos = best_pos;
+			auto it = std::partition(items.begin() + (long)begin, items.begin() + (long)end, [axis, pos](const Item& a) { return a.c[axis] < pos; });
+			mid = (size_t)(it - items.begin());
+			if (mid == begin || mid == end) best_axis = -1;  // numerical corner: fall through to the median
+		}
+		if (best_axis < 0) {
+			if (n <= (size_t)max_leaf) return sah_leaf(begin, end);
+			// no useful SAH split (coincident centroids, a forced balanced split, or a leaf too large): median of the widest centroid axis
+			int axis = 0;
+			for (int k = 1; k < 3; k++)
+				if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+			mid = begin + n / 2;
+			std::nth_element(items.begin() + (long)begin, items.begin() + (long)mid, items.begin() + (long)end, [axis](const Item& a, const Item& b) {
+				return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.id < b.id);
+			});
+		}
+		(void)best_left;
+		int32_t me = new_node();
+		Sub l = sah_build(begin, mid, depth + 1);
+		Sub r = sah_build(mid, end, depth + 1);
+		write_node(me, l, r);
+		if (depth + 1 > max_depth) max_depth = depth + 1;
+		return Sub{me, box_union(l.b64, r.b64), box_union(l.b32, r.b32)};
 	}
 };
 }  // namespace
@@ -445,9 +635,12 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	}
 	Builder b;
 	b.objs = objs;
+	b.n_objs = n;
 	b.out = out;
 	b.order.resize((size_t)n);
 	std::iota(b.order.begin(), b.order.end(), 0);
+	b.rank.assign((size_t)n, 0);
+	b.gate_word.assign((size_t)n, 0u);
 	out->mats64.resize((size_t)n);
 	out->mats32.resize((size_t)n);
 	for (int64_t i = 0; i < n; i++) {
@@ -455,23 +648,68 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		out->mats64[(size_t)i].param = objs[i].param;
 		out->mats32[(size_t)i].param = (float)objs[i].param;
 	}
-	if (n < 6) {
-		// The whole scene is one leaf: give the kernels a root whose left child is that leaf
-		// and whose right child is an empty leaf behind a box no ray can enter.
-		out->nodes64.emplace_back();
-		out->nodes32.emplace_back();
-		// sort as the reference does even for a single leaf (src/bvh.rs:49 runs before the match)
-		Builder::Sub l = b.build(0, (size_t)n, 0);
-		Builder::Sub r;
-		r.code = leaf_code(0, 0, 0);
-		for (int k = 0; k < 3; k++) { r.b64.lo[k] = r.b32.lo[k] = r.ref.lo[k] = INFINITY; r.b64.hi[k] = r.b32.hi[k] = r.ref.hi[k] = -INFINITY; }
-		b.write_node(0, l, r);  // the leaf's gate, if any, is the root's
-		out->depth = 1;
-	} else {
-		Builder::Sub root = b.build(0, (size_t)n, 0);
-		out->root_gate = b.gate_for(root);
-		out->depth = b.max_depth;
+	// 1. the reference's tree: ranks, leaf order, gates
+	int ref_root = b.ref_build(0, (size_t)n);
+	{
+		std::vector<int> chain;
+		int32_t next_rank = 0;
+		b.ref_annotate(ref_root, chain, &next_rank);
 	}
+	if (out->gates32.size() >= (1u << 16)) { *err = "too many gated spheres"; return false; }
+	// reference depth in inner-node levels (reported to callers)
+	{
+		std::vector<std::pair<int, int>> todo{{ref_root, 0}};
+		int d = 1;
+		while (!todo.empty()) {
+			auto [node, depth] = todo.back();
+			todo.pop_back();
+			const Builder::RefNode& rn = b.ref_nodes[(size_t)node];
+			if (rn.left >= 0) { d = std::max(d, depth + 1); todo.push_back({rn.left, depth + 1}); todo.push_back({rn.right, depth + 1}); }
+		}
+		out->ref_depth = d;
+	}
+	// 2. the device tree
+	const char* mode = std::getenv("RTHIP_TREE");
+	bool use_sah = !(mode && std::string(mode) == "ref");
+	if (const char* v = std::getenv("RTHIP_SAH_LEAF")) b.max_leaf = std::max(1, std::min(7, std::atoi(v)));
+	if (const char* v = std::getenv("RTHIP_SAH_CPRIM")) b.cost_prim = std::atof(v);
+	int32_t root = b.new_node();  // node 0 is the root
+	Builder::Sub l, r;
+	r.code = leaf_code(0, 0, 0);
+	r.b64 = r.b32 = empty_box();
+	if (use_sah) {
+		for (int64_t i = 0; i < n; i++) {
+			if (!b.can_be_hit((int32_t)i)) continue;
+			Builder::Item it;
+			it.id = (int32_t)i;
+			it.b = b.bounds64((int32_t)i);
+			for (int k = 0; k < 3; k++) it.c[k] = 0.5 * (it.b.lo[k] + it.b.hi[k]);
+			b.items.push_back(it);
+		}
+		size_t m = b.items.size();
+		if (m <= (size_t)b.max_leaf) {
+			l = m ? b.sah_leaf(0, m) : r;
+		} else {
+			// the root's two children are the two halves of the first split
+			out->nodes64.pop_back();
+			out->nodes32.pop_back();
+			Builder::Sub whole = b.sah_build(0, m, 0);
+			(void)whole;
+			root = 0;
+		}
+		if (m <= (size_t)b.max_leaf) { b.write_node(root, l, r); b.max_depth = 1; }
+	} else {
+		if (b.ref_nodes[(size_t)ref_root].left < 0) {
+			l = b.shape_ref(ref_root, 0);
+			b.write_node(root, l, r);
+			b.max_depth = 1;
+		} else {
+			out->nodes64.pop_back();
+			out->nodes32.pop_back();
+			b.shape_ref(ref_root, 0);
+		}
+	}
+	out->depth = std::max(1, b.max_depth);
 	if (out->depth > kStackMax) { *err = "tree deeper than the traversal stack"; return false; }
 	return true;
 }

@@ -34,10 +34,10 @@ struct FlatScene {
 	std::vector<Prim<double>> prims64;
 	std::vector<Mat<double>> mats64;
 	std::vector<Gate<double>> gates64;
-	int root_gate = -1;  // gate of the root itself, or -1
-	int depth = 0;     // levels of inner nodes on the longest root-to-leaf path
+	int depth = 0;      // device tree: levels of inner nodes on the longest root-to-leaf path
+	int ref_depth = 0;  // the same for the reference's tree
 	int n_leaves = 0;
-	std::vector<int32_t> leaf_ids;    // object ids, leaves left to right, reference order inside a leaf
+	std::vector<int32_t> leaf_ids;    // reference tree: object ids, leaves left to right, reference order inside a leaf
 	std::vector<int32_t> leaf_sizes;
 };
 // Returns false (with a message) for an empty scene or non-finite input.

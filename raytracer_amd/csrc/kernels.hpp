@@ -35,6 +35,15 @@
 
 namespace rthip {
 
+#ifndef RT_FUSED_BOX
+#define RT_FUSED_BOX 1
+#endif
+#ifndef RT_POSTPONE
+#define RT_POSTPONE 0
+#endif
+#ifndef RT_MINWAVES
+#define RT_MINWAVES 6
+#endif
 constexpr int kProbeBlock = 256;  // threads per workgroup of the parity probe
 constexpr int kDone = INT32_MIN;  // traversal finished (not a valid leaf code)
 
@@ -42,7 +51,6 @@ template <typename Real>
 struct RenderArgs {
 	const char* scene;  // [nodes | prims | mats | gates] blob in HBM, each part 64-byte aligned
 	uint32_t prims_off, mats_off, gates_off, scene_bytes;
-	int32_t root_gate;      // gate of the root itself, or -1
 	int32_t stack_entries;  // tree depth
 	CameraT<Real> cam;
 	int32_t width, height, tiles_x, tiles_y;
@@ -56,14 +64,13 @@ struct RenderArgs {
 	unsigned long long* accum;    // [tiles][64][4] fixed point
 	Real* samples_out;            // optional [spp_count][H][W][3]
 	uint32_t* queue;              // work-item counter, zeroed before the launch
-	unsigned long long* stats;    // [0] paths [1] rays [2] box tests [3] sphere tests [4] cube tests
+	unsigned long long* stats;    // [0] paths [1] rays [2] box tests [3] sphere tests [4] cube tests, then region counters
 };
 
 template <typename Real>
 struct ProbeArgs {
 	const char* scene;
 	uint32_t prims_off, mats_off, gates_off, scene_bytes;
-	int32_t root_gate;
 	int32_t stack_entries;
 	CameraT<Real> cam;
 	int32_t width, height;
@@ -223,31 +230,35 @@ RT_FN V3<Real> sky(V3<Real> dir, int sky_mode) {
 // ---------------------------------------------------------------------------------------
 template <typename Real> struct TravRay {
 	V3<Real> o, d, inv;  // inv = 1 / d
-	Real a, rcp_a;       // d.d and its reciprocal (f32 sphere test)
+	V3<Real> noi;        // -(o * inv): the f32 box test is one fma per plane, lo * inv + noi
+	Real eps;            // absolute slack that covers the rounding of that fma form
+	Real rcp_a;          // 1 / d.d (f32 sphere test)
 };
 RT_FN TravRay<Real> prepare(RayT<Real> r) {
 	TravRay<Real> t;
 	t.o = r.o; t.d = r.d;
 	t.inv = mk<Real>(Fp<Real>::rcp(r.d.x), Fp<Real>::rcp(r.d.y), Fp<Real>::rcp(r.d.z));
-	t.a = dot(r.d, r.d);
-	t.rcp_a = Fp<Real>::rcp(t.a);
+	t.noi = -(r.o * t.inv);
+	// lo*inv - o*inv is exact to an ulp of |o*inv| (not of the result): widen by 4 ulps of the largest term
+	t.eps = Fp<Real>::fmax(Fp<Real>::fmax(Fp<Real>::fabs(t.noi.x), Fp<Real>::fabs(t.noi.y)), Fp<Real>::fabs(t.noi.z)) * Real(0x1p-21);
+	t.rcp_a = Fp<Real>::rcp(dot(r.d, r.d));
 	return t;
 }
 
 // Sphere::hit, src/shapes/sphere.rs:26-48: the NEAR root only, direction not assumed unit.
 // f64: the reference's quadratic, literally.  f32: the same root written as
-//   t = (-(oc.d) - sqrt(a * (r^2 - |oc - ((oc.d)/a) d|^2))) / a
+//   t = -(oc.d)/a - sqrt((r^2 - |oc - ((oc.d)/a) d|^2) / a)
 // which keeps the discriminant accurate when |oc| >> r (small spheres far away, or the sun
 // sphere of radius 7500): b^2 - 4ac = 4a (r^2 - |q|^2) with q the closest approach to the centre.
 RT_FN bool hit_sphere(const Prim<Real>& s, const TravRay<Real>& r, Real* t) {
 	V3<Real> oc = r.o - ld3(s.v);
 	Real radius = s.v[3];
 	if constexpr (std::is_same<Real, float>::value) {
-		Real b = dot(oc, r.d);
-		V3<Real> q = oc - (b * r.rcp_a) * r.d;
+		Real tc = dot(oc, r.d) * r.rcp_a;  // -(parameter of the closest approach)
+		V3<Real> q = oc - tc * r.d;
 		Real disc = radius * radius - dot(q, q);
 		if (disc < 0.0f) return false;
-		*t = (-b - Fp<float>::sqrt(r.a * disc)) * r.rcp_a;
+		*t = -tc - Fp<float>::sqrt(disc * r.rcp_a);
 		return true;
 	} else {
 		Real a = dot(r.d, r.d);
@@ -290,25 +301,40 @@ RT_FN bool hit_cube(const Prim<Real>& c, const TravRay<Real>& r, Real* t) {
 
 // True slab test of one child box against (0.001, best_t].  The box distances and a primitive's
 // own t round differently (a cube's face and the face of the box around it are one plane
-// computed by two formulas), so the far side and the best_t bound are widened by a pad:
-// culling stays conservative, and two coplanar faces of different leaves still meet in the
-// (t, rank) comparison.  f32: 2^-18; f64: 2^-30 (covers the cancellation of the reference's
-// centre/half-extent cube formula for slabs of half extent 1e5).
+// computed by two formulas), so the far side is widened: culling stays conservative, and two
+// coplanar faces of different leaves still meet in the (t, rank) comparison.
+// f64: (plane - o) * inv per plane, relative pad 2^-30 (covers the cancellation of the
+// reference's centre/half-extent cube formula for slabs of half extent 1e5).
+// f32: one fma per plane (plane * inv - o * inv) and both interval ends folded into the
+// min3/max3 chains; its rounding is absolute (an ulp of |o * inv|), so the far side gets the
+// relative pad 2^-18 plus the ray's absolute slack eps.  A NaN plane distance (0 * inf on an
+// axis-parallel ray) drops out of min/max, which only makes the test more permissive.
 RT_FN bool hit_box(const Real* b, const TravRay<Real>& r, Real best_t, Real* entry) {
-	Real tx0 = (b[0] - r.o.x) * r.inv.x, tx1 = (b[3] - r.o.x) * r.inv.x;
-	Real ty0 = (b[1] - r.o.y) * r.inv.y, ty1 = (b[4] - r.o.y) * r.inv.y;
-	Real tz0 = (b[2] - r.o.z) * r.inv.z, tz1 = (b[5] - r.o.z) * r.inv.z;
-	Real tnear = Fp<Real>::fmax(Fp<Real>::fmax(Fp<Real>::fmin(tx0, tx1), Fp<Real>::fmin(ty0, ty1)), Fp<Real>::fmin(tz0, tz1));
-	Real tfar = Fp<Real>::fmin(Fp<Real>::fmin(Fp<Real>::fmax(tx0, tx1), Fp<Real>::fmax(ty0, ty1)), Fp<Real>::fmax(tz0, tz1));
-	*entry = tnear;
-	const Real pad = std::is_same<Real, float>::value ? Real(1.0 + 0x1p-18) : Real(1.0 + 0x1p-30);
-	tfar = tfar * pad;
-	return tnear <= tfar && tfar > Real(0.001) && tnear <= best_t * pad;
+	if constexpr (std::is_same<Real, float>::value && RT_FUSED_BOX) {
+		float x0 = __builtin_fmaf(b[0], r.inv.x, r.noi.x), x1 = __builtin_fmaf(b[3], r.inv.x, r.noi.x);
+		float y0 = __builtin_fmaf(b[1], r.inv.y, r.noi.y), y1 = __builtin_fmaf(b[4], r.inv.y, r.noi.y);
+		float z0 = __builtin_fmaf(b[2], r.inv.z, r.noi.z), z1 = __builtin_fmaf(b[5], r.inv.z, r.noi.z);
+		float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(x0, x1), Fp<float>::fmin(y0, y1)), Fp<float>::fmin(z0, z1));
+		float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(x0, x1), Fp<float>::fmax(y0, y1)),
+		                             Fp<float>::fmin(Fp<float>::fmax(z0, z1), best_t));
+		*entry = tnear;
+		return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, r.eps);
+	} else {
+		Real tx0 = (b[0] - r.o.x) * r.inv.x, tx1 = (b[3] - r.o.x) * r.inv.x;
+		Real ty0 = (b[1] - r.o.y) * r.inv.y, ty1 = (b[4] - r.o.y) * r.inv.y;
+		Real tz0 = (b[2] - r.o.z) * r.inv.z, tz1 = (b[5] - r.o.z) * r.inv.z;
+		Real tnear = Fp<Real>::fmax(Fp<Real>::fmax(Fp<Real>::fmin(tx0, tx1), Fp<Real>::fmin(ty0, ty1)), Fp<Real>::fmin(tz0, tz1));
+		Real tfar = Fp<Real>::fmin(Fp<Real>::fmin(Fp<Real>::fmax(tx0, tx1), Fp<Real>::fmax(ty0, ty1)), Fp<Real>::fmax(tz0, tz1));
+		*entry = tnear;
+		const Real pad = std::is_same<Real, float>::value ? Real(1.0 + 0x1p-18) : Real(1.0 + 0x1p-30);
+		tfar = tfar * pad;
+		return tnear <= tfar && tfar > Real(0.001) && tnear <= best_t * pad;
+	}
 }
 
 // AABB::hit, src/math.rs:356-371, as written: every axis is clipped against the constants
-// [0.001, MAX] on its own (the interval is not carried from axis to axis).  Only used on gate
-// boxes (see Gate in layout.hpp).
+// [0.001, MAX] on its own (the interval is not carried from axis to axis).  Only used on the
+// gate boxes of inverted spheres (see Gate in layout.hpp).
 RT_FN bool hit_box_reference(const Real* b, const TravRay<Real>& r) {
 	const Real kMax = std::is_same<Real, float>::value ? Real(3.402823466e+38) : Real(1.7976931348623157e+308);
 	const Real o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
@@ -332,76 +358,108 @@ RT_FN bool hit_box_reference(const Real* b, const TravRay<Real>& r) {
 // encodes that order so the result does not depend on the visiting order.
 // ---------------------------------------------------------------------------------------
 template <typename Real> struct Trav {
-	int32_t cur;   // >= 0 inner node, < 0 leaf code, kDone when finished
+	int32_t cur;      // >= 0 inner node, < 0 leaf code, kDone when finished
+	int32_t pending;  // a leaf met earlier and postponed (its code), 0 = none
 	int32_t sp;
 	Real best_t;
 	int32_t best_prim;  // index into prims, -1 = none
-	int32_t best_rank;
 };
-RT_FN void trav_begin(Trav<Real>& tv, const TravRay<Real>& r, const Gate<Real>* gates, int32_t root_gate) {
-	tv.cur = 0; tv.sp = 0; tv.best_t = Fp<Real>::inf(); tv.best_prim = -1; tv.best_rank = -1;
-	if (root_gate >= 0 && !hit_box_reference<Real>(gates[root_gate].box, r)) tv.cur = kDone;
+RT_FN void trav_begin(Trav<Real>& tv) {
+	tv.cur = 0; tv.pending = 0; tv.sp = 0; tv.best_t = Fp<Real>::inf(); tv.best_prim = -1;
 }
 struct Tally { uint32_t box, sphere, cube; };
-
-// Descends inner nodes until the lane reaches a leaf or runs out of work.
-template <typename Real, int kThreads, bool kCount>
-__device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, const Gate<Real>* gates, int* stack, Tally& tally) {
-	while (tv.cur >= 0) {
-		const Node<Real>& n = nodes[tv.cur];
-		Real el, er;
-		bool hl = hit_box<Real>(n.box, r, tv.best_t, &el);
-		bool hr = hit_box<Real>(n.box + 6, r, tv.best_t, &er);
-		int32_t cl = n.child[0], cr = n.child[1];
-		int32_t gl = n.gate[0], gr = n.gate[1];
-		if (hl && gl >= 0) hl = hit_box_reference<Real>(gates[gl].box, r);
-		if (hr && gr >= 0) hr = hit_box_reference<Real>(gates[gr].box, r);
-		if (kCount) tally.box += 2;
-		if (hl && hr) {
-			bool right_first = er < el;  // nearer child first, the left one on equal entry
-			stack[tv.sp * kThreads] = right_first ? cl : cr;
-			tv.sp++;
-			tv.cur = right_first ? cr : cl;
-		} else if (hl) {
-			tv.cur = cl;
-		} else if (hr) {
-			tv.cur = cr;
-		} else if (tv.sp > 0) {
-			tv.sp--;
-			tv.cur = stack[tv.sp * kThreads];
-		} else {
-			tv.cur = kDone;
-		}
+// Instrumented builds only: per code region, the lane-iterations executed (sum over active
+// lanes) and the wave-iterations issued (counted by the first active lane), whose ratio / 64
+// is the SIMD lane utilisation of that region.
+enum : int { kRegInner = 0, kRegSphere, kRegCube, kRegLeaf, kRegShade, kRegSky, kRegLambert, kRegMetal, kRegGlass, kRegStart, kRegTravRound, kRegCount };
+struct Regions { uint32_t lane[kRegCount], wave[kRegCount]; };
+template <bool kCount>
+__device__ __forceinline__ void region_tick(Regions& rg, int slot) {
+	if constexpr (kCount) {
+		rg.lane[slot]++;
+		unsigned long long m = __ballot(1);
+		if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) rg.wave[slot]++;
 	}
 }
-// Tests the primitives of the leaf in tv.cur, then pops.
-template <typename Real, int kThreads, bool kCount>
-__device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, int* stack, Tally& tally) {
-	uint32_t code = ~(uint32_t)tv.cur;
-	int32_t first = (int32_t)(code >> 6);
-	int32_t ns = (int32_t)((code >> 3) & 7u), nc = (int32_t)(code & 7u);
-	for (int32_t i = first; i < first + ns; i++) {
-		const Prim<Real>& p = prims[i];
-		Real t;
-		if (kCount) tally.sphere++;
-		if (hit_sphere<Real>(p, r, &t) && t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && p.rank > tv.best_rank))) {
-			tv.best_t = t; tv.best_prim = i; tv.best_rank = p.rank;
-		}
-	}
-	for (int32_t i = first + ns; i < first + ns + nc; i++) {
-		const Prim<Real>& p = prims[i];
-		Real t;
-		if (kCount) tally.cube++;
-		if (hit_cube<Real>(p, r, &t) && t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && p.rank > tv.best_rank))) {
-			tv.best_t = t; tv.best_prim = i; tv.best_rank = p.rank;
-		}
-	}
+
+template <typename Real, int kThreads>
+__device__ __forceinline__ void trav_pop(Trav<Real>& tv, const int* stack) {
 	if (tv.sp > 0) {
 		tv.sp--;
 		tv.cur = stack[tv.sp * kThreads];
 	} else {
 		tv.cur = kDone;
 	}
+}
+// Descends inner nodes.  The first leaf a lane meets is postponed (tv.pending) and the lane
+// keeps traversing, so that the lanes of a wave stay in this loop together for longer; the
+// lane stops at its second leaf or when it runs out of work.
+template <typename Real, int kThreads, bool kCount>
+__device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, int* stack, Tally& tally, Regions& rg) {
+	for (;;) {
+		if (tv.cur >= 0) {
+			region_tick<kCount>(rg, kRegInner);
+			const Node<Real>& n = nodes[tv.cur];
+			Real el, er;
+			bool hl = hit_box<Real>(n.box, r, tv.best_t, &el);
+			bool hr = hit_box<Real>(n.box + 6, r, tv.best_t, &er);
+			int32_t cl = n.child[0], cr = n.child[1];
+			if (kCount) tally.box += 2;
+			if (hl && hr) {
+				bool right_first = er < el;  // nearer child first, the left one on equal entry
+				stack[tv.sp * kThreads] = right_first ? cl : cr;
+				tv.sp++;
+				tv.cur = right_first ? cr : cl;
+			} else if (hl) {
+				tv.cur = cl;
+			} else if (hr) {
+				tv.cur = cr;
+			} else {
+				trav_pop<Real, kThreads>(tv, stack);
+			}
+		} else if (RT_POSTPONE && tv.cur != kDone && tv.pending == 0) {
+			tv.pending = tv.cur;
+			trav_pop<Real, kThreads>(tv, stack);
+		} else {
+			break;
+		}
+	}
+}
+// Tests the primitives of the postponed leaf and of the leaf in tv.cur (either may be absent)
+// as one run of spheres and one run of cubes, then pops.
+template <typename Real, int kThreads, bool kCount>
+__device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, const Gate<Real>* gates, int* stack, Tally& tally, Regions& rg) {
+	region_tick<kCount>(rg, kRegLeaf);
+	const bool cur_is_leaf = tv.cur != kDone;  // the caller guarantees tv.cur < 0
+	uint32_t ca = tv.pending != 0 ? ~(uint32_t)tv.pending : 0u;  // code 0 = leaf of nothing
+	uint32_t cb = cur_is_leaf ? ~(uint32_t)tv.cur : 0u;
+	int32_t fa = (int32_t)(ca >> 6), nsa = (int32_t)((ca >> 3) & 7u), nca = (int32_t)(ca & 7u);
+	int32_t fb = (int32_t)(cb >> 6), nsb = (int32_t)((cb >> 3) & 7u), ncb = (int32_t)(cb & 7u);
+	auto better = [&](Real t, int32_t i) {
+		return t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && prims[i].rank > prims[tv.best_prim].rank));
+	};
+	for (int32_t k = 0; k < nsa + nsb; k++) {
+		int32_t i = k < nsa ? fa + k : fb + (k - nsa);
+		Real t;
+		region_tick<kCount>(rg, kRegSphere);
+		if (kCount) tally.sphere++;
+		if (hit_sphere<Real>(prims[i], r, &t) && better(t, i)) {
+			// a gated (inverted) sphere counts only if the reference would have reached it
+			uint32_t gw = (uint32_t)prims[i].v[4];
+			bool reachable = true;
+			for (uint32_t g = 0; g < (gw & 255u); g++) reachable = reachable && hit_box_reference<Real>(gates[(gw >> 8) + g].box, r);
+			if (reachable) { tv.best_t = t; tv.best_prim = i; }
+		}
+	}
+	for (int32_t k = 0; k < nca + ncb; k++) {
+		int32_t i = k < nca ? fa + nsa + k : fb + nsb + (k - nca);
+		Real t;
+		region_tick<kCount>(rg, kRegCube);
+		if (kCount) tally.cube++;
+		if (hit_cube<Real>(prims[i], r, &t) && better(t, i)) { tv.best_t = t; tv.best_prim = i; }
+	}
+	tv.pending = 0;
+	if (cur_is_leaf) trav_pop<Real, kThreads>(tv, stack);
 }
 
 // BVH::trace, src/bvh.rs:130-142, with get_normal of src/shapes/sphere.rs:60-62 and
@@ -499,7 +557,7 @@ enum : int { kIdle = 0, kTraverse = 1, kShade = 2 };
 // The megakernel.
 // ---------------------------------------------------------------------------------------
 template <typename Real, int kThreads, bool kLds, bool kCount>
-__global__ __launch_bounds__(kThreads) void render_kernel(RenderArgs<Real> A) {
+__global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? RT_MINWAVES : 2)) void render_kernel(RenderArgs<Real> A) {
 	extern __shared__ __align__(64) char smem[];
 	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kThreads]
 	const uint32_t stack_bytes = (uint32_t)A.stack_entries * kThreads * 4u;
@@ -533,11 +591,12 @@ __global__ __launch_bounds__(kThreads) void render_kernel(RenderArgs<Real> A) {
 	Rng rng;
 	uint32_t accum_index = 0, sample_slot = 0;
 	Tally tally{0, 0, 0};
+	Regions rg{};
 	uint32_t n_rays = 0, n_paths = 0;
-	tv.cur = kDone; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1; tv.best_rank = -1;
+	tv.cur = kDone; tv.pending = 0; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
 	rng.state = 0; rng.inc = 1;
 	T = L = mk<Real>(0, 0, 0);
-	ray.o = ray.d = ray.inv = T; ray.a = ray.rcp_a = 0;
+	ray.o = ray.d = ray.inv = ray.noi = T; ray.eps = ray.rcp_a = 0;
 
 	// wave state (uniform)
 	uint32_t item = 0, pool_pos = 0, pool_end = 0;
@@ -579,9 +638,10 @@ __global__ __launch_bounds__(kThreads) void render_kernel(RenderArgs<Real> A) {
 						L = mk<Real>(0, 0, 0);
 						depth = A.max_depth;
 						n_paths++;
+						region_tick<kCount>(rg, kRegStart);
 						if (depth > 0) {
 							ray = prepare<Real>(r);
-							trav_begin<Real>(tv, ray, gates, A.root_gate);
+							trav_begin<Real>(tv);
 							state = kTraverse;
 						} else if (A.samples_out) {  // renderer.rs:10-12: depth <= 0 -> black
 							Real* so = A.samples_out + (size_t)sample_slot * 3;
@@ -604,17 +664,20 @@ __global__ __launch_bounds__(kThreads) void render_kernel(RenderArgs<Real> A) {
 				if (waiting != 0ull) break;
 			}
 			if (state == kTraverse) {
-				trav_inner<Real, kThreads, kCount>(tv, ray, nodes, gates, stack, tally);
-				if (tv.cur != kDone) trav_leaf<Real, kThreads, kCount>(tv, ray, prims, stack, tally);
+				region_tick<kCount>(rg, kRegTravRound);
+				trav_inner<Real, kThreads, kCount>(tv, ray, nodes, stack, tally, rg);
+				if (tv.cur != kDone || tv.pending != 0) trav_leaf<Real, kThreads, kCount>(tv, ray, prims, gates, stack, tally, rg);
 				if (tv.cur == kDone) state = kShade;
 			}
 		}
 
 		// ---- shading ---------------------------------------------------------------------
 		if (state == kShade) {
+			region_tick<kCount>(rg, kRegShade);
 			n_rays++;
 			bool finished = false;
 			if (tv.best_prim < 0) {
+				region_tick<kCount>(rg, kRegSky);
 				// renderer.rs:24: sky * contribution, unwound through the attenuations again
 				L = L + T * (sky<Real>(ray.d, A.sky_mode) * T);
 				finished = true;
@@ -624,6 +687,7 @@ __global__ __launch_bounds__(kThreads) void render_kernel(RenderArgs<Real> A) {
 				Hit<Real> h = make_hit<Real>(pr, is_sphere, ray, tv.best_t);
 				const Mat<Real>& mat = mats[h.id];
 				V3<Real> att, nd;
+				region_tick<kCount>(rg, h.material == RTHIP_LAMBERTIAN ? kRegLambert : (h.material == RTHIP_METAL ? kRegMetal : kRegGlass));
 				if (!scatter<Real>(h, mat, ray.d, rng, &att, &nd)) {
 					finished = true;  // renderer.rs:20-22: absorbed, this hit's emission is dropped
 				} else {
@@ -634,7 +698,7 @@ __global__ __launch_bounds__(kThreads) void render_kernel(RenderArgs<Real> A) {
 						finished = true;  // renderer.rs:10-12
 					} else {
 						ray = prepare<Real>(RayT<Real>{h.p, nd});
-						trav_begin<Real>(tv, ray, gates, A.root_gate);
+						trav_begin<Real>(tv);
 						state = kTraverse;
 					}
 				}
@@ -655,8 +719,11 @@ __global__ __launch_bounds__(kThreads) void render_kernel(RenderArgs<Real> A) {
 	}
 
 	// ---- statistics: one atomic per wave ------------------------------------------------
-	unsigned long long v[5] = {n_paths, n_rays, tally.box, tally.sphere, tally.cube};
-	const int nstat = kCount ? 5 : 2;
+	unsigned long long v[5 + 2 * kRegCount] = {n_paths, n_rays, tally.box, tally.sphere, tally.cube};
+	if constexpr (kCount) {
+		for (int k = 0; k < kRegCount; k++) { v[5 + k] = rg.lane[k]; v[5 + kRegCount + k] = rg.wave[k]; }
+	}
+	const int nstat = kCount ? 5 + 2 * kRegCount : 2;
 	for (int k = 0; k < nstat; k++) {
 		unsigned long long s = v[k];
 		for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -681,11 +748,12 @@ __global__ __launch_bounds__(kProbeBlock) void probe_kernel(ProbeArgs<Real> A) {
 	rng.init(A.seed, i, A.sample);
 	TravRay<Real> ray = prepare<Real>(camera_ray<Real>(A.cam, (Real)px, (Real)py, rng, A.jitter != 0));
 	Trav<Real> tv;
-	trav_begin<Real>(tv, ray, gates, A.root_gate);
+	trav_begin<Real>(tv);
 	Tally tally{0, 0, 0};
-	while (tv.cur != kDone) {
-		trav_inner<Real, kProbeBlock, false>(tv, ray, nodes, gates, stack, tally);
-		if (tv.cur != kDone) trav_leaf<Real, kProbeBlock, false>(tv, ray, prims, stack, tally);
+	Regions rg{};
+	while (tv.cur != kDone || tv.pending != 0) {
+		trav_inner<Real, kProbeBlock, false>(tv, ray, nodes, stack, tally, rg);
+		if (tv.cur != kDone || tv.pending != 0) trav_leaf<Real, kProbeBlock, false>(tv, ray, prims, gates, stack, tally, rg);
 	}
 	if (tv.best_prim < 0) {
 		A.id[i] = -1; A.t[i] = 0.0; A.front[i] = 0;

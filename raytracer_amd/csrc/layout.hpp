@@ -15,7 +15,7 @@ namespace rthip {
 
 constexpr int kTile = 8;              // tiles are 8x8 pixels = one wave of primary rays
 constexpr int kTilePixels = 64;
-constexpr int kStackMax = 24;         // per-lane traversal stack entries (tree depth limit)
+constexpr int kStackMax = 32;         // per-lane traversal stack entries (tree depth limit)
 constexpr int kAccumChannels = 4;     // r, g, b, unused: 32 bytes per pixel
 constexpr double kAccumScale = 68719476736.0;  // 2^36 fixed-point units per 1.0
 constexpr int kMatShift = 28;         // Prim::id = object id | material type << 28 | kind << 30
@@ -29,12 +29,11 @@ template <typename Real>
 struct alignas(sizeof(Real) * 16) Node {
 	Real box[12];      // left child lo.xyz hi.xyz, right child lo.xyz hi.xyz
 	int32_t child[2];  // left, right
-	int32_t gate[2];   // per child: index of its gate box, or -1 (see Gate)
 };
 static_assert(sizeof(Node<float>) == 64, "f32 node is one 64-byte line");
 static_assert(sizeof(Node<double>) == 128, "f64 node is 128 bytes");
 
-// Sphere: v = centre.xyz, radius, 0, 0.
+// Sphere: v = centre.xyz, radius, gate word (see Gate), 0.
 // Cube, f64: v = centre.xyz, half_extent.xyz (the reference's own representation).
 // Cube, f32: v = lo.xyz, hi.xyz, computed in f64 as centre -/+ half_extent and rounded once,
 //            so that huge cubes (ground slabs of half extent 1e5) keep exact faces.
@@ -49,13 +48,13 @@ static_assert(sizeof(Prim<double>) == 64, "f64 primitive is 64 bytes");
 
 // Gate box.  BVH::new (src/bvh.rs:53-56,68) unions the boxes objects cache, and a sphere of
 // negative radius caches an INVERTED box (src/shapes/sphere.rs:13-19) that adds nothing to a
-// union.  Where a split separates such an inner sphere from the outer shell that would have
-// covered it, the reference's box for the subtree is smaller than the subtree's true bounds,
-// and the reference reaches the inner sphere only for rays that pass its per-axis test
-// (src/math.rs:356-371) on that smaller box.  To return the same hits, a child whose
-// reference box differs from its true bounds carries that reference box as a gate: the ray
-// must pass the reference's test on it as well.  Everywhere else that test is implied by the
-// slab test and no gate is stored.
+// union.  Where a split of the reference's tree separates such an inner sphere from the outer
+// shell that would have covered it, the reference's boxes above it are smaller than its true
+// bounds, and the reference reaches it only for rays that pass its per-axis test
+// (src/math.rs:356-371) on those boxes.  Such a sphere carries those boxes as gates and counts
+// as hit only if the ray passes the reference's test on each of them (Prim::v[4] of a sphere
+// holds first_gate << 8 | n_gates as a number).  For every other object that test is implied
+// by hitting the object, and nothing is stored.
 template <typename Real>
 struct Gate {
 	Real box[6];  // lo.xyz hi.xyz as the reference computes them

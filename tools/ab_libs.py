@@ -1,0 +1,31 @@
+"""A/B of several builds of librthip (same ABI) on both bench workloads: one subprocess per
+build (a process can load only one), three rounds each, interleaved."""
+import os, subprocess, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+libs = sys.argv[1:]
+code = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import raytracer_amd as rt
+CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
+out = {}
+for which, scene, depth in (("cfg2", "default", 10), ("cfg3", "sample", 50)):
+    r = rt.Renderer(rt.Scene.generate(scene), rt.Camera(*CAM, 1920, 1080), max_depth=depth, seed=1)
+    best = 0
+    for _ in range(4):
+        r.reset_accumulation(); r.accumulate(32, spp_begin=0)
+        s = r.stats(); best = max(best, s["paths"] / s["kernel_ms"] / 1e3)
+    out[which] = best
+    r.close()
+print(json.dumps(out))
+''' % ROOT
+res = {l: [] for l in libs}
+for rnd in range(2):
+    for l in libs:
+        env = dict(os.environ, RTHIP_LIBRARY=os.path.join(ROOT, "raytracer_amd", l))
+        o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        if o.returncode != 0:
+            print(l, "FAILED", o.stderr[-400:]); continue
+        res[l].append(json.loads(o.stdout.strip().splitlines()[-1]))
+for l in libs:
+    print(l, " ".join(f"{k}: " + "/".join(f"{r[k]:.0f}" for r in res[l]) for k in ("cfg2", "cfg3")))
