@@ -21,6 +21,7 @@ thread_local std::string g_create_error;
 struct SceneBlob {  // one precision of the scene in HBM: [nodes | prims | mats]
 	char* dev = nullptr;
 	uint32_t prims_off = 0, mats_off = 0, gates_off = 0, bytes = 0;
+	uint32_t lds_bytes = 0;  // nodes + prims + gates: what an LDS-resident launch copies
 };
 inline uint32_t align_up(uint64_t v, uint32_t a) { return (uint32_t)((v + a - 1) / a * a); }
 }  // namespace
@@ -76,8 +77,8 @@ int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const st
                     const std::vector<Mat<Real>>& mats, const std::vector<Gate<Real>>& gates, SceneBlob* b) {
 	uint64_t nb = nodes.size() * sizeof(Node<Real>), pb = prims.size() * sizeof(Prim<Real>), mb = mats.size() * sizeof(Mat<Real>);
 	uint64_t gb = gates.size() * sizeof(Gate<Real>);
-	uint64_t prims_off = align_up(nb, 64), mats_off = align_up(prims_off + pb, 64), gates_off = align_up(mats_off + mb, 64);
-	uint64_t total = align_up(gates_off + gb, 64);
+	uint64_t prims_off = align_up(nb, 64), gates_off = align_up(prims_off + pb, 64), mats_off = align_up(gates_off + gb, 64);
+	uint64_t total = align_up(mats_off + mb, 64);
 	if (total > 0xFFFFFFF0ull) return fail(c, RTHIP_ERR_LIMIT, "scene larger than 4 GiB");
 	if (b->dev) { HIP_TRY(c, hipFree(b->dev)); b->dev = nullptr; }
 	std::vector<char> host((size_t)total, 0);
@@ -88,6 +89,7 @@ int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const st
 	HIP_TRY(c, hipMalloc(&b->dev, (size_t)total));
 	HIP_TRY(c, hipMemcpy(b->dev, host.data(), (size_t)total, hipMemcpyHostToDevice));
 	b->prims_off = (uint32_t)prims_off; b->mats_off = (uint32_t)mats_off; b->gates_off = (uint32_t)gates_off; b->bytes = (uint32_t)total;
+	b->lds_bytes = (uint32_t)mats_off;
 	return RTHIP_OK;
 }
 
@@ -122,7 +124,7 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	const bool f64 = p->precision == RTHIP_F64;
 	const SceneBlob& blob = f64 ? c->blob64 : c->blob32;
 	int lds_mode = env_int("RTHIP_SCENE_LDS", -1);
-	bool in_lds = lds_mode < 0 ? blob.bytes <= kLdsSceneLimit : (lds_mode != 0 && blob.bytes <= 100 * 1024);
+	bool in_lds = lds_mode < 0 ? blob.lds_bytes <= kLdsSceneLimit : (lds_mode != 0 && blob.lds_bytes <= 100 * 1024);
 	plan->cfg.scene_in_lds = in_lds;
 	plan->cfg.count = count;
 	// Workgroup size: the kernel is latency bound, so pick the size that keeps the most waves
@@ -132,7 +134,7 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	int best_waves = -1, bpc = 0;
 	for (int threads : {256, 512}) {
 		if (forced && threads != forced) continue;
-		size_t lds = (size_t)c->tree_depth * threads * 4 + (in_lds ? blob.bytes : 0);
+		size_t lds = (size_t)c->tree_depth * threads * 4 + (in_lds ? blob.lds_bytes : 0);
 		int b = 0;
 		HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, in_lds, lds, &b) : render_blocks_per_cu_f32(threads, in_lds, lds, &b));
 		if (b * threads / 64 > best_waves) {
@@ -167,6 +169,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	RenderArgs<Real> a;
 	std::memset(&a, 0, sizeof(a));
 	a.scene = blob.dev; a.prims_off = blob.prims_off; a.mats_off = blob.mats_off; a.gates_off = blob.gates_off; a.scene_bytes = blob.bytes;
+	a.lds_bytes = blob.lds_bytes;
 	a.stack_entries = c->tree_depth;
 	fill_camera<Real>(c->cam, &a.cam);
 	a.width = c->cam.width; a.height = c->cam.height; a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y;

@@ -49,8 +49,9 @@ constexpr int kDone = INT32_MIN;  // traversal finished (not a valid leaf code)
 
 template <typename Real>
 struct RenderArgs {
-	const char* scene;  // [nodes | prims | mats | gates] blob in HBM, each part 64-byte aligned
+	const char* scene;  // [nodes | prims | gates | mats] blob in HBM, each part 64-byte aligned
 	uint32_t prims_off, mats_off, gates_off, scene_bytes;
+	uint32_t lds_bytes;     // leading part of the blob that LDS-resident launches copy (all but the materials)
 	int32_t stack_entries;  // tree depth
 	CameraT<Real> cam;
 	int32_t width, height, tiles_x, tiles_y;
@@ -568,11 +569,11 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	if constexpr (kLds) {
 		char* dst = smem + stack_bytes;
 		const uint4* src = reinterpret_cast<const uint4*>(A.scene);
-		for (uint32_t i = threadIdx.x; i < A.scene_bytes / 16u; i += kThreads) reinterpret_cast<uint4*>(dst)[i] = src[i];
+		for (uint32_t i = threadIdx.x; i < A.lds_bytes / 16u; i += kThreads) reinterpret_cast<uint4*>(dst)[i] = src[i];
 		__syncthreads();
 		nodes = reinterpret_cast<const Node<Real>*>(dst);
 		prims = reinterpret_cast<const Prim<Real>*>(dst + A.prims_off);
-		mats = reinterpret_cast<const Mat<Real>*>(dst + A.mats_off);
+		mats = reinterpret_cast<const Mat<Real>*>(A.scene + A.mats_off);  // read once per ray: left in HBM / L2
 		gates = reinterpret_cast<const Gate<Real>*>(dst + A.gates_off);
 	} else {
 		nodes = reinterpret_cast<const Node<Real>*>(A.scene);
