@@ -124,10 +124,11 @@ int32_t rthip_synchronize(rthip_ctx* ctx);
 /* raytracer_runtime/src/main.rs:102-103 (accum_image cleared on a camera change). */
 int32_t rthip_reset_accumulation(rthip_ctx* ctx);
 
-/* The accumulation buffer: one uint64 per channel, 4 channels (r, g, b, unused) per pixel,
- * counting units of 2^-36; pixels are stored tile-major (8x8 tiles, row-major inside a tile).
+/* The accumulation buffer: uint64 words counting units of 2^-36, laid out
+ * [tile][channel r,g,b][64 pixels] over the 8x8 tiles of the image in row-major tile order
+ * (pixels row-major inside a tile): word = (tile * 3 + channel) * 64 + (y % 8) * 8 + (x % 8).
  * Integer sums make merges across GPUs exact and order-independent.  The pointer is device
- * memory owned by the context; n_words = tiles_x * tiles_y * 64 * 4. */
+ * memory owned by the context; n_words = tiles_x * tiles_y * 192. */
 int32_t rthip_accum_buffer(rthip_ctx* ctx, void** device_ptr, uint64_t* n_words);
 /* Use caller-owned device memory of n_words uint64 (e.g. a torch tensor, so that it can be
  * handed to an RCCL collective) as the accumulation buffer; NULL returns to the own buffer. */

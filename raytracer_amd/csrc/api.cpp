@@ -387,7 +387,7 @@ int32_t rthip_set_accum_buffer(rthip_ctx* c, void* device_ptr, uint64_t n_words)
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	if (!device_ptr) { c->accum = nullptr; c->accum_words = 0; return ensure_accum(c); }
 	uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
-	if (n_words != words) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must hold tiles_x*tiles_y*64*4 words");
+	if (n_words != words) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must hold tiles_x*tiles_y*192 words");
 	if (reinterpret_cast<uintptr_t>(device_ptr) % 8) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must be 8-byte aligned");
 	c->accum = static_cast<unsigned long long*>(device_ptr); c->accum_words = words;
 	return RTHIP_OK;

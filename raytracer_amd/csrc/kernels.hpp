@@ -62,7 +62,7 @@ struct RenderArgs {
 	int32_t part_index, part_count;
 	uint32_t n_items, chunk, n_chunks;
 	int32_t trav_threshold;
-	unsigned long long* accum;    // [tiles][64][4] fixed point
+	unsigned long long* accum;    // [tiles][3 channels][64 px] fixed point
 	Real* samples_out;            // optional [spp_count][H][W][3]
 	uint32_t* queue;              // work-item counter, zeroed before the launch
 	unsigned long long* stats;    // [0] paths [1] rays [2] box tests [3] sphere tests [4] cube tests, then region counters
@@ -540,12 +540,22 @@ RT_FN bool scatter(const Hit<Real>& h, const Mat<Real>& m, V3<Real> dir_in, Rng&
 
 // sqrt(radiance) -> fixed point (2^-36 units).  NaN and negatives count as 0; one sample is
 // capped at 256 (radiance 65536), far above anything a display shows, so sums cannot wrap
-// below 2^20 samples per pixel.
+// below 2^20 samples per pixel.  f32: the value has 24 significant bits, so splitting it into
+// an integer part in 2^-4 units and a 32-bit fraction of that is exact and needs two
+// hardware conversions instead of an emulated 64-bit one.
 RT_FN unsigned long long to_fixed(Real v) {
-	double x = (double)v;
-	if (!(x > 0.0)) return 0ull;
-	if (x > 256.0) x = 256.0;
-	return (unsigned long long)(x * kAccumScale + 0.5);
+	if constexpr (std::is_same<Real, float>::value) {
+		float x = v * 16.0f;                        // units of 2^-4; NaN stays NaN
+		x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 4096.0f);  // NaN -> 0, cap at 256
+		float hi = __builtin_truncf(x);
+		float lo = (x - hi) * 4294967296.0f;        // fraction in units of 2^-36, < 2^32, exact
+		return ((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo;
+	} else {
+		double x = (double)v;
+		if (!(x > 0.0)) return 0ull;
+		if (x > 256.0) x = 256.0;
+		return (unsigned long long)(x * kAccumScale + 0.5);
+	}
 }
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
@@ -710,10 +720,24 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 					so[0] = L.x; so[1] = L.y; so[2] = L.z;
 				}
 				// raytracer_headless/src/main.rs:53: gamma (sqrt) per sample, then summed
-				unsigned long long* acc = A.accum + (size_t)accum_index * kAccumChannels;
+				// tile-major, one 64-word plane per channel: the lanes of a wave that finish together
+				// touch few cache lines per atomic instruction
+				unsigned long long* acc = A.accum + (size_t)(accum_index >> 6) * (kTilePixels * kAccumChannels) + (accum_index & 63u);
+#if defined(RT_ACC_STORE)
+				acc[0] = to_fixed<Real>(Fp<Real>::sqrt(L.x)); acc[1] = to_fixed<Real>(Fp<Real>::sqrt(L.y)); acc[2] = to_fixed<Real>(Fp<Real>::sqrt(L.z));
+#elif defined(RT_ACC_U32)
+				atomicAdd(reinterpret_cast<unsigned int*>(acc + 0), (unsigned int)to_fixed<Real>(Fp<Real>::sqrt(L.x)));
+				atomicAdd(reinterpret_cast<unsigned int*>(acc + kTilePixels), (unsigned int)to_fixed<Real>(Fp<Real>::sqrt(L.y)));
+				atomicAdd(reinterpret_cast<unsigned int*>(acc + 2 * kTilePixels), (unsigned int)to_fixed<Real>(Fp<Real>::sqrt(L.z)));
+#elif defined(RT_ACC_ONE)
+				atomicAdd(acc + 0, to_fixed<Real>(Fp<Real>::sqrt(L.x)) + to_fixed<Real>(Fp<Real>::sqrt(L.y)) + to_fixed<Real>(Fp<Real>::sqrt(L.z)));
+#elif !defined(RT_NO_ACCUM)
 				atomicAdd(acc + 0, to_fixed<Real>(Fp<Real>::sqrt(L.x)));
-				atomicAdd(acc + 1, to_fixed<Real>(Fp<Real>::sqrt(L.y)));
-				atomicAdd(acc + 2, to_fixed<Real>(Fp<Real>::sqrt(L.z)));
+				atomicAdd(acc + kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L.y)));
+				atomicAdd(acc + 2 * kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L.z)));
+#else
+				if (L.x == Real(-1)) acc[0] = 1;  // experiment: keep L alive, no accumulation traffic
+#endif
 				state = kIdle;
 			}
 		}

@@ -7,13 +7,13 @@ namespace rthip {
 
 __device__ __forceinline__ size_t accum_offset(uint32_t x, uint32_t y, int tiles_x) {
 	uint32_t tile = (y / kTile) * (uint32_t)tiles_x + (x / kTile);
-	return ((size_t)tile * kTilePixels + (y % kTile) * kTile + (x % kTile)) * kAccumChannels;
+	return (size_t)tile * (kTilePixels * kAccumChannels) + (y % kTile) * kTile + (x % kTile);  // + channel * kTilePixels
 }
 __global__ void unpack_accum_kernel(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x) {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (uint32_t)width * (uint32_t)height) return;
 	size_t src = accum_offset(i % (uint32_t)width, i / (uint32_t)width, tiles_x);
-	for (int c = 0; c < 3; c++) rgb[(size_t)i * 3 + c] = (double)accum[src + c] * (1.0 / kAccumScale);
+	for (int c = 0; c < 3; c++) rgb[(size_t)i * 3 + c] = (double)accum[src + c * kTilePixels] * (1.0 / kAccumScale);
 }
 // `(v * 255.0) as u8` of Rust: truncation toward zero, saturating, NaN -> 0.
 __device__ __forceinline__ uint32_t quantize(unsigned long long fixed, double spp) {
@@ -26,7 +26,7 @@ __global__ void finalize_kernel(const unsigned long long* accum, void* out, int 
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (uint32_t)width * (uint32_t)height) return;
 	size_t src = accum_offset(i % (uint32_t)width, i / (uint32_t)width, tiles_x);
-	uint32_t r = quantize(accum[src], (double)spp), g = quantize(accum[src + 1], (double)spp), b = quantize(accum[src + 2], (double)spp);
+	uint32_t r = quantize(accum[src], (double)spp), g = quantize(accum[src + kTilePixels], (double)spp), b = quantize(accum[src + 2 * kTilePixels], (double)spp);
 	if (xrgb) {
 		static_cast<uint32_t*>(out)[i] = (r << 16) | (g << 8) | b;
 	} else {

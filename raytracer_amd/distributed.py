@@ -29,7 +29,7 @@ def tile_part(rank, world):
 
 
 def accum_words(width, height):
-    return ((width + 7) // 8) * ((height + 7) // 8) * 64 * 4
+    return ((width + 7) // 8) * ((height + 7) // 8) * 64 * 3
 
 
 def new_accum_tensor(width, height, device):
@@ -49,6 +49,6 @@ def accum_to_image(accum, width, height):
     """Decode a (merged) accumulation buffer to sum_s sqrt(sample), float64 [H, W, 3], on the host."""
     words = accum.detach().cpu().numpy().view(np.uint64)
     tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
-    a = words.reshape(tiles_y, tiles_x, 8, 8, 4)
-    img = a.transpose(0, 2, 1, 3, 4).reshape(tiles_y * 8, tiles_x * 8, 4)[:height, :width, :3]
+    a = words.reshape(tiles_y, tiles_x, 3, 8, 8)  # [tile row][tile col][channel][y in tile][x in tile]
+    img = a.transpose(0, 3, 1, 4, 2).reshape(tiles_y * 8, tiles_x * 8, 3)[:height, :width]
     return img.astype(np.float64) / 2.0 ** 36

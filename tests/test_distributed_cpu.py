@@ -71,4 +71,4 @@ def test_partitions_cover_everything_once():
         tiles = np.arange(240 * 135)
         owners = sum(((tiles % world) == D.tile_part(r, world)[0]).astype(int) for r in range(world))
         assert (owners == 1).all()
-    assert D.accum_words(1920, 1080) == 240 * 135 * 256
+    assert D.accum_words(1920, 1080) == 240 * 135 * 192

@@ -156,5 +156,5 @@ def test_accum_word_packing_roundtrip():
     rng = np.random.default_rng(0)
     img = rng.uniform(0, 50, (23, 37, 3))
     words = pack_accum_words(img, 37, 23)
-    assert words.size == 5 * 3 * 64 * 4
+    assert words.size == 5 * 3 * 64 * 3
     assert np.abs(unpack_accum_words(words, 37, 23) - img).max() <= 2.0 ** -37

@@ -23,16 +23,16 @@ SCENES = ["default", "sample", "simple", "glass", "metal", "wallpaper"]
 
 
 def unpack_accum_words(words, width, height):
-    """Host-side decoding of the accumulation buffer (tile-major, 2^-36 fixed point)."""
+    """Host-side decoding of the accumulation buffer ([tile][channel][64 px], 2^-36 fixed point)."""
     tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
-    a = np.asarray(words, dtype=np.uint64).reshape(tiles_y, tiles_x, 8, 8, 4)
-    img = a.transpose(0, 2, 1, 3, 4).reshape(tiles_y * 8, tiles_x * 8, 4)[:height, :width, :3]
+    a = np.asarray(words, dtype=np.uint64).reshape(tiles_y, tiles_x, 3, 8, 8)
+    img = a.transpose(0, 3, 1, 4, 2).reshape(tiles_y * 8, tiles_x * 8, 3)[:height, :width]
     return img.astype(np.float64) / 2.0 ** 36
 
 
 def pack_accum_words(img, width, height):
     """Inverse of unpack_accum_words for an [H, W, 3] array of sums."""
     tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
-    full = np.zeros((tiles_y * 8, tiles_x * 8, 4), dtype=np.uint64)
-    full[:height, :width, :3] = np.floor(np.asarray(img) * 2.0 ** 36 + 0.5).astype(np.uint64)
-    return full.reshape(tiles_y, 8, tiles_x, 8, 4).transpose(0, 2, 1, 3, 4).reshape(-1).copy()
+    full = np.zeros((tiles_y * 8, tiles_x * 8, 3), dtype=np.uint64)
+    full[:height, :width] = np.floor(np.asarray(img) * 2.0 ** 36 + 0.5).astype(np.uint64)
+    return full.reshape(tiles_y, 8, tiles_x, 8, 3).transpose(0, 2, 4, 1, 3).reshape(-1).copy()
