@@ -157,11 +157,13 @@ class Renderer:
     progressive loop of raytracer_runtime/src/main.rs:69-94 (update_camera / reset_accumulation
     / frame counter follow the shape of raytracer_gpu/src/renderer.rs:484-587)."""
 
-    def __init__(self, scene, camera, device=0, max_depth=10, seed=0x5EED0001, sky_mode=N.SKY_REFERENCE, precision=N.F32):
+    def __init__(self, scene, camera, device=0, max_depth=10, seed=0x5EED0001, sky_mode=N.SKY_REFERENCE, precision=N.F32,
+                 variant=N.MEGAKERNEL):
         self._lib = N.lib()
         self._ctx = C.c_void_p()
         N.check(self._lib.rthip_create(int(device), C.byref(self._ctx)))
         self.max_depth, self.seed, self.sky_mode, self.precision = max_depth, seed, sky_mode, precision
+        self.variant = variant  # MEGAKERNEL (persistent threads) or WAVEFRONT (generate / extend / shade per bounce)
         self.spp_done = 0
         objs = scene.objects if isinstance(scene, Scene) else scene.scene.objects
         self._objs = np.ascontiguousarray(objs, dtype=N.OBJECT_DTYPE)
@@ -206,7 +208,7 @@ class Renderer:
     def _params(self, spp_begin, spp_count, part=(0, 1), precision=None):
         p = N.RenderParams()
         p.spp_begin, p.spp_count, p.max_depth, p.seed = spp_begin, spp_count, self.max_depth, self.seed
-        p.sky_mode, p.precision, p.variant = self.sky_mode, self.precision if precision is None else precision, N.MEGAKERNEL
+        p.sky_mode, p.precision, p.variant = self.sky_mode, self.precision if precision is None else precision, self.variant
         p.part_index, p.part_count = part
         return p
 

@@ -46,6 +46,10 @@ struct rthip_ctx {
 	uint64_t accum_words = 0;
 
 	char* d_control = nullptr;  // 512 bytes: queue counter at +0, statistics words from +8
+	// wavefront variant: ping-pong path state, hit records and the per-bounce counter block
+	char* wf_mem = nullptr;
+	size_t wf_bytes = 0;
+	uint32_t* wf_counters = nullptr;  // kWfMaxDepth + 1 queue sizes, then kWfMaxDepth work counters
 	rthip_stats stats{};
 	bool launch_pending = false;
 	bool last_in_lds = false;
@@ -100,6 +104,7 @@ int env_int(const char* name, int dflt) {
 
 // Scenes up to this size are copied into LDS by every workgroup of the render kernel.
 constexpr uint32_t kLdsSceneLimit = 64 * 1024;
+constexpr int kWfMaxDepth = 4096;
 
 struct Plan {
 	LaunchCfg cfg;
@@ -113,14 +118,15 @@ int32_t validate(rthip_ctx* c, const rthip_render_params* p) {
 	if (!c->has_scene || !c->has_camera) return fail(c, RTHIP_ERR_STATE, "upload a scene and set a camera first");
 	if (p->precision != RTHIP_F32 && p->precision != RTHIP_F64) return fail(c, RTHIP_ERR_INVALID, "precision must be RTHIP_F32 or RTHIP_F64");
 	if (p->sky_mode != RTHIP_SKY_REFERENCE && p->sky_mode != RTHIP_SKY_WALLPAPER) return fail(c, RTHIP_ERR_INVALID, "unknown sky_mode");
-	if (p->variant != RTHIP_MEGAKERNEL) return fail(c, RTHIP_ERR_INVALID, "unknown variant");
+	if (p->variant != RTHIP_MEGAKERNEL && p->variant != RTHIP_WAVEFRONT) return fail(c, RTHIP_ERR_INVALID, "unknown variant");
+	if (p->variant == RTHIP_WAVEFRONT && p->max_depth > kWfMaxDepth) return fail(c, RTHIP_ERR_LIMIT, "the wavefront variant supports max_depth <= 4096");
 	if (p->part_count < 1 || p->part_index < 0 || p->part_index >= p->part_count) return fail(c, RTHIP_ERR_INVALID, "bad tile partition");
 	if (p->reserved[0] || p->reserved[1] || p->reserved[2]) return fail(c, RTHIP_ERR_INVALID, "reserved fields must be zero");
 	if ((uint64_t)p->spp_begin + p->spp_count > 0xFFFFFFFFull) return fail(c, RTHIP_ERR_INVALID, "sample range overflows");
 	return RTHIP_OK;
 }
 
-int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* plan) {
+int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* plan, bool wavefront = false) {
 	const bool f64 = p->precision == RTHIP_F64;
 	const SceneBlob& blob = f64 ? c->blob64 : c->blob32;
 	int lds_mode = env_int("RTHIP_SCENE_LDS", -1);
@@ -136,7 +142,8 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 		if (forced && threads != forced) continue;
 		size_t lds = (size_t)c->tree_depth * threads * 4 + (in_lds ? blob.lds_bytes : 0);
 		int b = 0;
-		HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, in_lds, lds, &b) : render_blocks_per_cu_f32(threads, in_lds, lds, &b));
+		if (wavefront) HIP_TRY(c, f64 ? wf_extend_blocks_per_cu_f64(threads, in_lds, lds, &b) : wf_extend_blocks_per_cu_f32(threads, in_lds, lds, &b));
+		else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, in_lds, lds, &b) : render_blocks_per_cu_f32(threads, in_lds, lds, &b));
 		if (b * threads / 64 > best_waves) {
 			best_waves = b * threads / 64; bpc = b;
 			plan->cfg.threads = threads; plan->cfg.dyn_lds = lds;
@@ -182,6 +189,81 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 512, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
 	if (plan.n_items > 0 && p->spp_count > 0) HIP_TRY(c, launch_render(a, plan.cfg, c->stream));
+	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+	c->launch_pending = true;
+	c->last_in_lds = plan.cfg.scene_in_lds;
+	return RTHIP_OK;
+}
+
+// Wavefront variant: batches of paths go through generate, then extend + shade per bounce.
+template <typename Real>
+int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned long long* accum, Real* samples_out) {
+	Plan plan;
+	int32_t rc = make_plan(c, p, false, &plan, true);
+	if (rc != RTHIP_OK) return rc;
+	const SceneBlob& blob = std::is_same<Real, double>::value ? c->blob64 : c->blob32;
+	const uint64_t per_item = (uint64_t)kTilePixels * plan.chunk;
+	const uint64_t total = (uint64_t)plan.n_items * per_item;
+	uint64_t batch = (uint64_t)std::max(1, env_int("RTHIP_WF_BATCH", 8 << 20));
+	batch = std::min<uint64_t>(std::max<uint64_t>(batch, per_item), std::max<uint64_t>(total, 1));
+	if (batch > 0xFFFFFF00ull) batch = 0xFFFFFF00ull;
+	// carve the state memory: two states (3 quads + meta + slot) and the hit records
+	const size_t quad = sizeof(Quad<Real>);
+	auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+	const size_t state_bytes = 3 * up(batch * quad) + up(batch * 16) + up(batch * 4);
+	const size_t need = 2 * state_bytes + up(batch * sizeof(Real)) + up(batch * 4);
+	if (c->wf_bytes < need) {
+		if (c->wf_mem) { HIP_TRY(c, hipFree(c->wf_mem)); c->wf_mem = nullptr; c->wf_bytes = 0; }
+		HIP_TRY(c, hipMalloc(&c->wf_mem, need));
+		c->wf_bytes = need;
+	}
+	if (!c->wf_counters) HIP_TRY(c, hipMalloc(&c->wf_counters, (2 * kWfMaxDepth + 2) * sizeof(uint32_t)));
+	WfState<Real> st[2];
+	char* m = c->wf_mem;
+	for (int k = 0; k < 2; k++) {
+		st[k].q0 = reinterpret_cast<Quad<Real>*>(m); m += up(batch * quad);
+		st[k].q1 = reinterpret_cast<Quad<Real>*>(m); m += up(batch * quad);
+		st[k].q2 = reinterpret_cast<Quad<Real>*>(m); m += up(batch * quad);
+		st[k].q3 = reinterpret_cast<uint4*>(m); m += up(batch * 16);
+		st[k].slot = samples_out ? reinterpret_cast<uint32_t*>(m) : nullptr; m += up(batch * 4);
+	}
+	WfArgs<Real> a;
+	std::memset(&a, 0, sizeof(a));
+	a.hit_t = reinterpret_cast<Real*>(m); m += up(batch * sizeof(Real));
+	a.hit_prim = reinterpret_cast<int32_t*>(m);
+	a.scene = blob.dev; a.prims_off = blob.prims_off; a.mats_off = blob.mats_off; a.gates_off = blob.gates_off;
+	a.scene_bytes = blob.bytes; a.lds_bytes = blob.lds_bytes; a.stack_entries = c->tree_depth;
+	fill_camera<Real>(c->cam, &a.cam);
+	a.width = c->cam.width; a.height = c->cam.height; a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y;
+	a.spp_begin = p->spp_begin; a.spp_count = p->spp_count; a.max_depth = p->max_depth; a.seed = p->seed; a.sky_mode = p->sky_mode;
+	a.part_index = p->part_index; a.part_count = p->part_count; a.chunk = plan.chunk; a.n_chunks = plan.n_chunks;
+	a.accum = accum; a.samples_out = samples_out;
+	a.stats = reinterpret_cast<unsigned long long*>(c->d_control + 8);
+	const int stream_grid = c->num_cu * 2;  // workgroups of 1024 threads
+	const int depth = std::max(0, p->max_depth);
+	uint32_t* n = c->wf_counters;
+	uint32_t* fetch = c->wf_counters + kWfMaxDepth + 1;
+	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 512, c->stream));
+	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+	for (uint64_t begin = 0; begin < total && p->spp_count > 0; begin += batch) {
+		HIP_TRY(c, hipMemsetAsync(c->wf_counters, 0, (2 * kWfMaxDepth + 2) * sizeof(uint32_t), c->stream));
+		a.path_begin = begin;
+		a.path_count = (uint32_t)std::min<uint64_t>(batch, total - begin);
+		a.out = st[0]; a.n_out = n;
+		HIP_TRY(c, launch_wf_generate(a, stream_grid, c->stream));
+		for (int b = 0; b < depth; b++) {
+			a.in = st[b & 1]; a.out = st[(b + 1) & 1];
+			a.n_in = n + b; a.n_out = n + b + 1; a.fetch = fetch + b;
+			HIP_TRY(c, launch_wf_extend(a, plan.cfg, c->stream));
+			HIP_TRY(c, launch_wf_shade(a, stream_grid, c->stream));
+			if ((b & 7) == 7 && b + 1 < depth) {  // long paths: stop launching once the queue is empty
+				uint32_t left = 0;
+				HIP_TRY(c, hipMemcpyAsync(&left, n + b + 1, sizeof(left), hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(c, hipStreamSynchronize(c->stream));
+				if (left == 0) break;
+			}
+		}
+	}
 	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
 	c->launch_pending = true;
 	c->last_in_lds = plan.cfg.scene_in_lds;
@@ -266,6 +348,8 @@ void rthip_destroy(rthip_ctx* c) {
 	if (c->blob64.dev) (void)hipFree(c->blob64.dev);
 	if (c->own_accum) (void)hipFree(c->own_accum);
 	if (c->d_control) (void)hipFree(c->d_control);
+	if (c->wf_mem) (void)hipFree(c->wf_mem);
+	if (c->wf_counters) (void)hipFree(c->wf_counters);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -341,6 +425,10 @@ int32_t rthip_render_accumulate_async(rthip_ctx* c, const rthip_render_params* p
 	if ((rc = collect_stats(c)) != RTHIP_OK) return rc;  // the control block is reused per launch
 	if ((rc = ensure_accum(c)) != RTHIP_OK) return rc;
 	bool count = env_int("RTHIP_COUNT", 0) != 0;
+	if (p->variant == RTHIP_WAVEFRONT) {
+		if (p->precision == RTHIP_F64) return enqueue_wavefront<double>(c, p, c->accum, nullptr);
+		return enqueue_wavefront<float>(c, p, c->accum, nullptr);
+	}
 	if (p->precision == RTHIP_F64) return enqueue_render<double>(c, p, count, c->accum, nullptr);
 	return enqueue_render<float>(c, p, count, c->accum, nullptr);
 }
@@ -493,7 +581,10 @@ int32_t rthip_render_samples(rthip_ctx* c, const rthip_render_params* p, double*
 	(void)hipMemsetAsync(d_samples, 0, n * elem, c->stream);
 	(void)hipMemsetAsync(d_scratch, 0, words * 8, c->stream);
 	bool count = env_int("RTHIP_COUNT", 0) != 0;
-	if (p->precision == RTHIP_F64) rc = enqueue_render<double>(c, p, count, d_scratch, reinterpret_cast<double*>(d_samples));
+	if (p->variant == RTHIP_WAVEFRONT) {
+		if (p->precision == RTHIP_F64) rc = enqueue_wavefront<double>(c, p, d_scratch, reinterpret_cast<double*>(d_samples));
+		else rc = enqueue_wavefront<float>(c, p, d_scratch, reinterpret_cast<float*>(d_samples));
+	} else if (p->precision == RTHIP_F64) rc = enqueue_render<double>(c, p, count, d_scratch, reinterpret_cast<double*>(d_samples));
 	else rc = enqueue_render<float>(c, p, count, d_scratch, reinterpret_cast<float*>(d_samples));
 	if (rc == RTHIP_OK) rc = collect_stats(c);
 	if (rc == RTHIP_OK) {

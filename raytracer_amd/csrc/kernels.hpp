@@ -562,6 +562,54 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// One bounce of ray_color (src/renderer.rs:14-25) in its unrolled form:
+//   miss     -> L += T * (sky * T), the path ends      (:24; the sky term is unwound through the attenuations again)
+//   absorbed -> the path ends, this hit's emission is dropped (:20-22)
+//   else     -> L += T * emission, T *= attenuation, depth - 1; depth 0 ends the path (:10-12)
+// Returns true when the path continues along *next.
+RT_FN bool shade_ray(const TravRay<Real>& ray, Real best_t, int32_t best_prim, const Prim<Real>* prims, const Mat<Real>* mats,
+                     int sky_mode, Rng& rng, V3<Real>& T, V3<Real>& L, int32_t& depth, RayT<Real>* next) {
+	if (best_prim < 0) {
+		L = L + T * (sky<Real>(ray.d, sky_mode) * T);
+		return false;
+	}
+	const Prim<Real>& pr = prims[best_prim];
+	Hit<Real> h = make_hit<Real>(pr, ((pr.id >> kKindShift) & 1) == RTHIP_SPHERE, ray, best_t);
+	const Mat<Real>& mat = mats[h.id];
+	V3<Real> att, nd;
+	if (!scatter<Real>(h, mat, ray.d, rng, &att, &nd)) return false;
+	if (h.material == RTHIP_LAMBERTIAN) L = L + T * (ld3(mat.albedo) * mat.param);  // materials.rs:71-77
+	T = T * att;
+	depth--;
+	if (depth <= 0) return false;
+	next->o = h.p;
+	next->d = nd;
+	return true;
+}
+// raytracer_headless/src/main.rs:53: gamma (sqrt) per sample, then summed.  The buffer is
+// [tile][channel][64 px]: the lanes of a wave that finish together touch few cache lines per
+// atomic instruction.
+RT_FN void accumulate_sample(unsigned long long* accum, uint32_t accum_index, V3<Real> L) {
+	unsigned long long* acc = accum + (size_t)(accum_index >> 6) * (kTilePixels * kAccumChannels) + (accum_index & 63u);
+	atomicAdd(acc, to_fixed<Real>(Fp<Real>::sqrt(L.x)));
+	atomicAdd(acc + kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L.y)));
+	atomicAdd(acc + 2 * kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L.z)));
+}
+// Work-item decoding shared by every variant: path j of work item `item` (an 8x8 tile x `chunk`
+// samples).  Returns false for pixels outside the image and samples beyond spp_count.
+struct PathId { uint32_t px, py, accum_index, s_local; };
+__device__ __forceinline__ bool decode_path(uint32_t item, uint32_t j, uint32_t n_chunks, uint32_t chunk, uint32_t spp_count,
+                                            int32_t part_index, int32_t part_count, int32_t tiles_x, int32_t width, int32_t height, PathId* out) {
+	uint32_t tile_local = item / n_chunks, chunk_i = item - tile_local * n_chunks;
+	uint32_t tile = (uint32_t)part_index + tile_local * (uint32_t)part_count;
+	uint32_t ty = tile / (uint32_t)tiles_x, tx = tile - ty * (uint32_t)tiles_x;
+	out->px = tx * kTile + (j & 7u);
+	out->py = ty * kTile + ((j >> 3) & 7u);
+	out->s_local = chunk_i * chunk + (j >> 6);
+	out->accum_index = tile * kTilePixels + (j & 63u);
+	return out->px < (uint32_t)width && out->py < (uint32_t)height && out->s_local < spp_count;
+}
+
 enum : int { kIdle = 0, kTraverse = 1, kShade = 2 };
 
 // ---------------------------------------------------------------------------------------
@@ -633,18 +681,12 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			if (state == kIdle) {
 				uint32_t rk = lane_rank(need);
 				if (rk < take) {
-					uint32_t j = pool_pos + rk;
-					uint32_t tile_local = item / A.n_chunks, chunk_i = item - tile_local * A.n_chunks;
-					uint32_t tile = (uint32_t)A.part_index + tile_local * (uint32_t)A.part_count;
-					uint32_t ty = tile / (uint32_t)A.tiles_x, tx = tile - ty * (uint32_t)A.tiles_x;
-					uint32_t px = tx * kTile + (j & 7u), py = ty * kTile + ((j >> 3) & 7u);
-					uint32_t s_local = chunk_i * A.chunk + (j >> 6);
-					if (px < (uint32_t)A.width && py < (uint32_t)A.height && s_local < A.spp_count) {
-						uint32_t pixel = py * (uint32_t)A.width + px;
-						rng.init(A.seed, pixel, A.spp_begin + s_local);
-						RayT<Real> r = camera_ray<Real>(A.cam, (Real)px, (Real)py, rng, true);
-						accum_index = tile * kTilePixels + (j & 63u);
-						sample_slot = (s_local * (uint32_t)A.height + py) * (uint32_t)A.width + px;
+					PathId id;
+					if (decode_path(item, pool_pos + rk, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id)) {
+						rng.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
+						RayT<Real> r = camera_ray<Real>(A.cam, (Real)id.px, (Real)id.py, rng, true);
+						accum_index = id.accum_index;
+						sample_slot = (id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px;
 						T = mk<Real>(1, 1, 1);
 						L = mk<Real>(0, 0, 0);
 						depth = A.max_depth;
@@ -686,58 +728,17 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 		if (state == kShade) {
 			region_tick<kCount>(rg, kRegShade);
 			n_rays++;
-			bool finished = false;
-			if (tv.best_prim < 0) {
-				region_tick<kCount>(rg, kRegSky);
-				// renderer.rs:24: sky * contribution, unwound through the attenuations again
-				L = L + T * (sky<Real>(ray.d, A.sky_mode) * T);
-				finished = true;
+			RayT<Real> next;
+			if (shade_ray<Real>(ray, tv.best_t, tv.best_prim, prims, mats, A.sky_mode, rng, T, L, depth, &next)) {
+				ray = prepare<Real>(next);
+				trav_begin<Real>(tv);
+				state = kTraverse;
 			} else {
-				const Prim<Real>& pr = prims[tv.best_prim];
-				bool is_sphere = ((pr.id >> kKindShift) & 1) == RTHIP_SPHERE;
-				Hit<Real> h = make_hit<Real>(pr, is_sphere, ray, tv.best_t);
-				const Mat<Real>& mat = mats[h.id];
-				V3<Real> att, nd;
-				region_tick<kCount>(rg, h.material == RTHIP_LAMBERTIAN ? kRegLambert : (h.material == RTHIP_METAL ? kRegMetal : kRegGlass));
-				if (!scatter<Real>(h, mat, ray.d, rng, &att, &nd)) {
-					finished = true;  // renderer.rs:20-22: absorbed, this hit's emission is dropped
-				} else {
-					if (h.material == RTHIP_LAMBERTIAN) L = L + T * (ld3(mat.albedo) * mat.param);  // materials.rs:71-77
-					T = T * att;
-					depth--;
-					if (depth <= 0) {
-						finished = true;  // renderer.rs:10-12
-					} else {
-						ray = prepare<Real>(RayT<Real>{h.p, nd});
-						trav_begin<Real>(tv);
-						state = kTraverse;
-					}
-				}
-			}
-			if (finished) {
 				if (A.samples_out) {
 					Real* so = A.samples_out + (size_t)sample_slot * 3;
 					so[0] = L.x; so[1] = L.y; so[2] = L.z;
 				}
-				// raytracer_headless/src/main.rs:53: gamma (sqrt) per sample, then summed
-				// tile-major, one 64-word plane per channel: the lanes of a wave that finish together
-				// touch few cache lines per atomic instruction
-				unsigned long long* acc = A.accum + (size_t)(accum_index >> 6) * (kTilePixels * kAccumChannels) + (accum_index & 63u);
-#if defined(RT_ACC_STORE)
-				acc[0] = to_fixed<Real>(Fp<Real>::sqrt(L.x)); acc[1] = to_fixed<Real>(Fp<Real>::sqrt(L.y)); acc[2] = to_fixed<Real>(Fp<Real>::sqrt(L.z));
-#elif defined(RT_ACC_U32)
-				atomicAdd(reinterpret_cast<unsigned int*>(acc + 0), (unsigned int)to_fixed<Real>(Fp<Real>::sqrt(L.x)));
-				atomicAdd(reinterpret_cast<unsigned int*>(acc + kTilePixels), (unsigned int)to_fixed<Real>(Fp<Real>::sqrt(L.y)));
-				atomicAdd(reinterpret_cast<unsigned int*>(acc + 2 * kTilePixels), (unsigned int)to_fixed<Real>(Fp<Real>::sqrt(L.z)));
-#elif defined(RT_ACC_ONE)
-				atomicAdd(acc + 0, to_fixed<Real>(Fp<Real>::sqrt(L.x)) + to_fixed<Real>(Fp<Real>::sqrt(L.y)) + to_fixed<Real>(Fp<Real>::sqrt(L.z)));
-#elif !defined(RT_NO_ACCUM)
-				atomicAdd(acc + 0, to_fixed<Real>(Fp<Real>::sqrt(L.x)));
-				atomicAdd(acc + kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L.y)));
-				atomicAdd(acc + 2 * kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L.z)));
-#else
-				if (L.x == Real(-1)) acc[0] = 1;  // experiment: keep L alive, no accumulation traffic
-#endif
+				accumulate_sample<Real>(A.accum, accum_index, L);
 				state = kIdle;
 			}
 		}

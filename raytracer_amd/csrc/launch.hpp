@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
+#include "wavefront.hpp"
 
 namespace rthip {
 
@@ -27,5 +28,17 @@ hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width
 // raytracer_headless/src/main.rs:6-12,55: (accum / spp * 255.0) as u8.  xrgb = 0: RGB8 bytes
 // [H][W][3]; xrgb = 1: one 0x00RRGGBB word per pixel (raytracer_runtime/src/main.rs:15-17).
 hipError_t launch_finalize(const unsigned long long* accum, void* out, int width, int height, int tiles_x, unsigned spp, int xrgb, hipStream_t s);
+
+
+// Wavefront variant: one launcher per stage.  `grid` = workgroups of kWfStreamThreads for the
+// streaming stages; extend is configured like the megakernel (threads, dynamic LDS, scene in LDS).
+hipError_t launch_wf_generate(const WfArgs<float>& a, int grid, hipStream_t s);
+hipError_t launch_wf_generate(const WfArgs<double>& a, int grid, hipStream_t s);
+hipError_t launch_wf_extend(const WfArgs<float>& a, const LaunchCfg& cfg, hipStream_t s);
+hipError_t launch_wf_extend(const WfArgs<double>& a, const LaunchCfg& cfg, hipStream_t s);
+hipError_t launch_wf_shade(const WfArgs<float>& a, int grid, hipStream_t s);
+hipError_t launch_wf_shade(const WfArgs<double>& a, int grid, hipStream_t s);
+hipError_t wf_extend_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks);
+hipError_t wf_extend_blocks_per_cu_f64(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks);
 
 }  // namespace rthip

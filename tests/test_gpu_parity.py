@@ -270,3 +270,52 @@ def test_large_synthetic_scene_f64_vs_oracle(rt, oracle):
     g32 = r.trace_primary(rt.F32, jitter=True, sample=1)
     assert (g32[0] != ref[0]).mean() <= 2e-3
     r.close()
+
+
+@pytest.mark.parametrize("scene,depth", [("default", 10), ("sample", 50), ("glass", 10), ("wallpaper", 10)])
+def test_wavefront_variant_f64_bit_exact(rt, oracle, renderers, scene, depth):
+    """The wavefront kernels (generate / extend / shade over ray queues in HBM) follow the same
+    paths as the oracle: per-sample radiance bit for bit, and the same ray count."""
+    w, h, spp = 96, 54, 3
+    r, sc = renderers(scene, w, h, seed=21)
+    r.max_depth = depth
+    r.variant = rt.WAVEFRONT
+    try:
+        got = r.render_samples(spp, precision=rt.F64)
+        rays = r.stats()["rays"]
+        osc = oracle.OracleScene(sc.objects)
+        _, ref, cnt, _ = osc.render(oracle.camera_desc(*camera_args(scene, w, h, rt)), spp, depth, 21, oracle.TIGHT, samples=True)
+        assert np.array_equal(got, ref) and rays == cnt["rays"]
+        r.variant = rt.MEGAKERNEL
+        mega = r.render_samples(spp, precision=rt.F64)
+        assert np.array_equal(got, mega) and r.stats()["rays"] == rays
+    finally:
+        r.variant = rt.MEGAKERNEL
+        r.max_depth = 10
+
+
+def test_wavefront_variant_accumulation(rt, renderers):
+    """Same integer sums as the megakernel in f64; f32 differs only by instruction contraction
+    inside shading (bounded here); batches smaller than the frame and tile parts give the same
+    words as one launch."""
+    w, h, spp = 200, 120, 4
+    r, _ = renderers("default", w, h, seed=22)
+    try:
+        for prec in (rt.F64, rt.F32):
+            r.precision = prec
+            r.variant = rt.MEGAKERNEL; r.reset_accumulation(); r.accumulate(spp); a = r.read_accum()
+            r.variant = rt.WAVEFRONT; r.reset_accumulation(); r.accumulate(spp); b = r.read_accum()
+            assert r.stats()["paths"] == w * h * spp
+            if prec == rt.F64:
+                assert np.array_equal(a, b)
+            else:
+                assert np.sqrt(np.mean((a - b) ** 2)) / spp < 2e-3
+            r.reset_accumulation()
+            for part in range(3):
+                r.accumulate(spp, part=(part, 3), spp_begin=0)
+            assert np.array_equal(r.read_accum(), b)
+            r.reset_accumulation(); r.accumulate(1, spp_begin=0); r.accumulate(spp - 1, spp_begin=1)
+            assert np.array_equal(r.read_accum(), b)
+    finally:
+        r.variant = rt.MEGAKERNEL
+        r.precision = rt.F32
