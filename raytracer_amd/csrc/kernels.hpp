@@ -239,9 +239,26 @@ RT_FN TravRay<Real> prepare(RayT<Real> r) {
 	TravRay<Real> t;
 	t.o = r.o; t.d = r.d;
 	t.inv = mk<Real>(Fp<Real>::rcp(r.d.x), Fp<Real>::rcp(r.d.y), Fp<Real>::rcp(r.d.z));
+	if constexpr (std::is_same<Real, float>::value && RT_FUSED_BOX) {
+		// A zero (or flushed) direction component gives inv = inf and plane * inf - o * inf = NaN for
+		// every plane; a huge finite stand-in keeps the sign of (plane - o), which is all that axis
+		// contributes for such a ray.
+		t.inv.x = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(t.inv.x), 0x1p64f), t.inv.x);
+		t.inv.y = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(t.inv.y), 0x1p64f), t.inv.y);
+		t.inv.z = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(t.inv.z), 0x1p64f), t.inv.z);
+	}
 	t.noi = -(r.o * t.inv);
-	// lo*inv - o*inv is exact to an ulp of |o*inv| (not of the result): widen by 4 ulps of the largest term
-	t.eps = Fp<Real>::fmax(Fp<Real>::fmax(Fp<Real>::fabs(t.noi.x), Fp<Real>::fabs(t.noi.y)), Fp<Real>::fabs(t.noi.z)) * Real(0x1p-21);
+	// plane*inv - o*inv is exact to an ulp of |o*inv| (not of the result): widen by 4 ulps of the
+	// largest term.  Only axes the ray actually advances along count (|d_a| >= 2^-12 max|d|): on a
+	// nearly parallel axis that ulp, however many time units it is, is still one ulp of o_a in
+	// space, and it can only drop a box whose face the ray skims within that distance; counting it
+	// would make the slack exceed every box of the scene and the ray visit the whole tree.
+	Real ax = Fp<Real>::fabs(r.d.x), ay = Fp<Real>::fabs(r.d.y), az = Fp<Real>::fabs(r.d.z);
+	Real floor_d = Fp<Real>::fmax(Fp<Real>::fmax(ax, ay), az) * Real(0x1p-12);
+	Real ex = ax >= floor_d ? Fp<Real>::fabs(t.noi.x) : Real(0);
+	Real ey = ay >= floor_d ? Fp<Real>::fabs(t.noi.y) : Real(0);
+	Real ez = az >= floor_d ? Fp<Real>::fabs(t.noi.z) : Real(0);
+	t.eps = Fp<Real>::fmax(Fp<Real>::fmax(ex, ey), ez) * Real(0x1p-21);
 	t.rcp_a = Fp<Real>::rcp(dot(r.d, r.d));
 	return t;
 }
@@ -308,8 +325,8 @@ RT_FN bool hit_cube(const Prim<Real>& c, const TravRay<Real>& r, Real* t) {
 // reference's centre/half-extent cube formula for slabs of half extent 1e5).
 // f32: one fma per plane (plane * inv - o * inv) and both interval ends folded into the
 // min3/max3 chains; its rounding is absolute (an ulp of |o * inv|), so the far side gets the
-// relative pad 2^-18 plus the ray's absolute slack eps.  A NaN plane distance (0 * inf on an
-// axis-parallel ray) drops out of min/max, which only makes the test more permissive.
+// relative pad 2^-18 plus the ray's absolute slack eps (see prepare()).  A NaN plane distance
+// drops out of min/max, which only makes the test more permissive.
 RT_FN bool hit_box(const Real* b, const TravRay<Real>& r, Real best_t, Real* entry) {
 	if constexpr (std::is_same<Real, float>::value && RT_FUSED_BOX) {
 		float x0 = __builtin_fmaf(b[0], r.inv.x, r.noi.x), x1 = __builtin_fmaf(b[3], r.inv.x, r.noi.x);
@@ -320,6 +337,15 @@ RT_FN bool hit_box(const Real* b, const TravRay<Real>& r, Real best_t, Real* ent
 		                             Fp<float>::fmin(Fp<float>::fmax(z0, z1), best_t));
 		*entry = tnear;
 		return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, r.eps);
+	} else if constexpr (std::is_same<Real, float>::value) {
+		float x0 = (b[0] - r.o.x) * r.inv.x, x1 = (b[3] - r.o.x) * r.inv.x;
+		float y0 = (b[1] - r.o.y) * r.inv.y, y1 = (b[4] - r.o.y) * r.inv.y;
+		float z0 = (b[2] - r.o.z) * r.inv.z, z1 = (b[5] - r.o.z) * r.inv.z;
+		float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(x0, x1), Fp<float>::fmin(y0, y1)), Fp<float>::fmin(z0, z1));
+		float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(x0, x1), Fp<float>::fmax(y0, y1)),
+		                             Fp<float>::fmin(Fp<float>::fmax(z0, z1), best_t));
+		*entry = tnear;
+		return Fp<float>::fmax(tnear, 0.0009f) <= tfar * (1.0f + 0x1p-18f);
 	} else {
 		Real tx0 = (b[0] - r.o.x) * r.inv.x, tx1 = (b[3] - r.o.x) * r.inv.x;
 		Real ty0 = (b[1] - r.o.y) * r.inv.y, ty1 = (b[4] - r.o.y) * r.inv.y;
