@@ -443,10 +443,11 @@ struct Builder {
 		const Sub* ch[2] = {&l, &r};
 		for (int c = 0; c < 2; c++) {
 			for (int k = 0; k < 3; k++) {
-				n64.box[6 * c + k] = ch[c]->b64.lo[k];
-				n64.box[6 * c + 3 + k] = ch[c]->b64.hi[k];
-				n32.box[6 * c + k] = round_down(ch[c]->b32.lo[k]);
-				n32.box[6 * c + 3 + k] = round_up(ch[c]->b32.hi[k]);
+				static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+				n64.box[6 * c + lo_slot[k]] = ch[c]->b64.lo[k];
+				n64.box[6 * c + hi_slot[k]] = ch[c]->b64.hi[k];
+				n32.box[6 * c + lo_slot[k]] = round_down(ch[c]->b32.lo[k]);
+				n32.box[6 * c + hi_slot[k]] = round_up(ch[c]->b32.hi[k]);
 			}
 			n64.child[c] = ch[c]->code;
 			n32.child[c] = ch[c]->code;

@@ -38,9 +38,6 @@ namespace rthip {
 #ifndef RT_FUSED_BOX
 #define RT_FUSED_BOX 1
 #endif
-#ifndef RT_POSTPONE
-#define RT_POSTPONE 0
-#endif
 #ifndef RT_MINWAVES
 #define RT_MINWAVES 6
 #endif
@@ -62,6 +59,7 @@ struct RenderArgs {
 	int32_t part_index, part_count;
 	uint32_t n_items, chunk, n_chunks;
 	int32_t trav_threshold;
+	int32_t inner_exit;     // sixteenths: leave the inner-node loop when fewer lanes than this share of the round remain in it
 	unsigned long long* accum;    // [tiles][3 channels][64 px] fixed point
 	Real* samples_out;            // optional [spp_count][H][W][3]
 	uint32_t* queue;              // work-item counter, zeroed before the launch
@@ -229,11 +227,15 @@ RT_FN V3<Real> sky(V3<Real> dir, int sky_mode) {
 // ---------------------------------------------------------------------------------------
 // A ray prepared for traversal.
 // ---------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
 template <typename Real> struct TravRay {
 	V3<Real> o, d, inv;  // inv = 1 / d
-	V3<Real> noi;        // -(o * inv): the f32 box test is one fma per plane, lo * inv + noi
+	V3<Real> noi;        // -(o * inv): the f32 box test is one fma per plane, plane * inv + noi
 	Real eps;            // absolute slack that covers the rounding of that fma form
 	Real rcp_a;          // 1 / d.d (f32 sphere test)
+	// f32 box test operands as register pairs for the packed FMA: (inv.x, inv.y), (noi.x, noi.y),
+	// (inv.z, inv.z), (noi.z, noi.z).  Unused (and dropped by the compiler) in f64.
+	f2 inv_xy, noi_xy, inv_zz, noi_zz;
 };
 RT_FN TravRay<Real> prepare(RayT<Real> r) {
 	TravRay<Real> t;
@@ -260,6 +262,8 @@ RT_FN TravRay<Real> prepare(RayT<Real> r) {
 	Real ez = az >= floor_d ? Fp<Real>::fabs(t.noi.z) : Real(0);
 	t.eps = Fp<Real>::fmax(Fp<Real>::fmax(ex, ey), ez) * Real(0x1p-21);
 	t.rcp_a = Fp<Real>::rcp(dot(r.d, r.d));
+	t.inv_xy = f2{(float)t.inv.x, (float)t.inv.y}; t.noi_xy = f2{(float)t.noi.x, (float)t.noi.y};
+	t.inv_zz = f2{(float)t.inv.z, (float)t.inv.z}; t.noi_zz = f2{(float)t.noi.z, (float)t.noi.z};
 	return t;
 }
 
@@ -329,33 +333,32 @@ RT_FN bool hit_cube(const Prim<Real>& c, const TravRay<Real>& r, Real* t) {
 // drops out of min/max, which only makes the test more permissive.
 RT_FN bool hit_box(const Real* b, const TravRay<Real>& r, Real best_t, Real* entry) {
 	if constexpr (std::is_same<Real, float>::value && RT_FUSED_BOX) {
-		float x0 = __builtin_fmaf(b[0], r.inv.x, r.noi.x), x1 = __builtin_fmaf(b[3], r.inv.x, r.noi.x);
-		float y0 = __builtin_fmaf(b[1], r.inv.y, r.noi.y), y1 = __builtin_fmaf(b[4], r.inv.y, r.noi.y);
-		float z0 = __builtin_fmaf(b[2], r.inv.z, r.noi.z), z1 = __builtin_fmaf(b[5], r.inv.z, r.noi.z);
-		float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(x0, x1), Fp<float>::fmin(y0, y1)), Fp<float>::fmin(z0, z1));
-		float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(x0, x1), Fp<float>::fmax(y0, y1)),
-		                             Fp<float>::fmin(Fp<float>::fmax(z0, z1), best_t));
+		const f2* p = reinterpret_cast<const f2*>(b);
+		f2 lo = __builtin_elementwise_fma(p[0], r.inv_xy, r.noi_xy);  // v_pk_fma_f32: two planes per instruction
+		f2 hi = __builtin_elementwise_fma(p[1], r.inv_xy, r.noi_xy);
+		f2 zz = __builtin_elementwise_fma(p[2], r.inv_zz, r.noi_zz);
+		float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(lo.x, hi.x), Fp<float>::fmin(lo.y, hi.y)), Fp<float>::fmin(zz.x, zz.y));
+		float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(lo.x, hi.x), Fp<float>::fmax(lo.y, hi.y)),
+		                             Fp<float>::fmin(Fp<float>::fmax(zz.x, zz.y), best_t));
 		*entry = tnear;
 		return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, r.eps);
-	} else if constexpr (std::is_same<Real, float>::value) {
-		float x0 = (b[0] - r.o.x) * r.inv.x, x1 = (b[3] - r.o.x) * r.inv.x;
-		float y0 = (b[1] - r.o.y) * r.inv.y, y1 = (b[4] - r.o.y) * r.inv.y;
-		float z0 = (b[2] - r.o.z) * r.inv.z, z1 = (b[5] - r.o.z) * r.inv.z;
-		float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(x0, x1), Fp<float>::fmin(y0, y1)), Fp<float>::fmin(z0, z1));
-		float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(x0, x1), Fp<float>::fmax(y0, y1)),
-		                             Fp<float>::fmin(Fp<float>::fmax(z0, z1), best_t));
-		*entry = tnear;
-		return Fp<float>::fmax(tnear, 0.0009f) <= tfar * (1.0f + 0x1p-18f);
 	} else {
-		Real tx0 = (b[0] - r.o.x) * r.inv.x, tx1 = (b[3] - r.o.x) * r.inv.x;
-		Real ty0 = (b[1] - r.o.y) * r.inv.y, ty1 = (b[4] - r.o.y) * r.inv.y;
-		Real tz0 = (b[2] - r.o.z) * r.inv.z, tz1 = (b[5] - r.o.z) * r.inv.z;
+		Real tx0 = (b[kBoxLoX] - r.o.x) * r.inv.x, tx1 = (b[kBoxHiX] - r.o.x) * r.inv.x;
+		Real ty0 = (b[kBoxLoY] - r.o.y) * r.inv.y, ty1 = (b[kBoxHiY] - r.o.y) * r.inv.y;
+		Real tz0 = (b[kBoxLoZ] - r.o.z) * r.inv.z, tz1 = (b[kBoxHiZ] - r.o.z) * r.inv.z;
 		Real tnear = Fp<Real>::fmax(Fp<Real>::fmax(Fp<Real>::fmin(tx0, tx1), Fp<Real>::fmin(ty0, ty1)), Fp<Real>::fmin(tz0, tz1));
-		Real tfar = Fp<Real>::fmin(Fp<Real>::fmin(Fp<Real>::fmax(tx0, tx1), Fp<Real>::fmax(ty0, ty1)), Fp<Real>::fmax(tz0, tz1));
-		*entry = tnear;
-		const Real pad = std::is_same<Real, float>::value ? Real(1.0 + 0x1p-18) : Real(1.0 + 0x1p-30);
-		tfar = tfar * pad;
-		return tnear <= tfar && tfar > Real(0.001) && tnear <= best_t * pad;
+		if constexpr (std::is_same<Real, float>::value) {  // separately rounded form: relative error only, no slack term
+			float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(tx0, tx1), Fp<float>::fmax(ty0, ty1)),
+			                             Fp<float>::fmin(Fp<float>::fmax(tz0, tz1), best_t));
+			*entry = tnear;
+			return Fp<float>::fmax(tnear, 0.0009f) <= tfar * (1.0f + 0x1p-18f);
+		} else {
+			Real tfar = Fp<Real>::fmin(Fp<Real>::fmin(Fp<Real>::fmax(tx0, tx1), Fp<Real>::fmax(ty0, ty1)), Fp<Real>::fmax(tz0, tz1));
+			*entry = tnear;
+			const Real pad = Real(1.0 + 0x1p-30);
+			tfar = tfar * pad;
+			return tnear <= tfar && tfar > Real(0.001) && tnear <= best_t * pad;
+		}
 	}
 }
 
@@ -386,13 +389,12 @@ RT_FN bool hit_box_reference(const Real* b, const TravRay<Real>& r) {
 // ---------------------------------------------------------------------------------------
 template <typename Real> struct Trav {
 	int32_t cur;      // >= 0 inner node, < 0 leaf code, kDone when finished
-	int32_t pending;  // a leaf met earlier and postponed (its code), 0 = none
 	int32_t sp;
 	Real best_t;
 	int32_t best_prim;  // index into prims, -1 = none
 };
 RT_FN void trav_begin(Trav<Real>& tv) {
-	tv.cur = 0; tv.pending = 0; tv.sp = 0; tv.best_t = Fp<Real>::inf(); tv.best_prim = -1;
+	tv.cur = 0; tv.sp = 0; tv.best_t = Fp<Real>::inf(); tv.best_prim = -1;
 }
 struct Tally { uint32_t box, sphere, cube; };
 // Instrumented builds only: per code region, the lane-iterations executed (sum over active
@@ -418,55 +420,47 @@ __device__ __forceinline__ void trav_pop(Trav<Real>& tv, const int* stack) {
 		tv.cur = kDone;
 	}
 }
-// Descends inner nodes.  The first leaf a lane meets is postponed (tv.pending) and the lane
-// keeps traversing, so that the lanes of a wave stay in this loop together for longer; the
-// lane stops at its second leaf or when it runs out of work.
+// Descends inner nodes until the lane stands at a leaf or has run out of work, or until most
+// lanes that entered with it have (it then stays at its inner node for the next round).
 template <typename Real, int kThreads, bool kCount>
-__device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, int* stack, Tally& tally, Regions& rg) {
-	for (;;) {
-		if (tv.cur >= 0) {
-			region_tick<kCount>(rg, kRegInner);
-			const Node<Real>& n = nodes[tv.cur];
-			Real el, er;
-			bool hl = hit_box<Real>(n.box, r, tv.best_t, &el);
-			bool hr = hit_box<Real>(n.box + 6, r, tv.best_t, &er);
-			int32_t cl = n.child[0], cr = n.child[1];
-			if (kCount) tally.box += 2;
-			if (hl && hr) {
-				bool right_first = er < el;  // nearer child first, the left one on equal entry
-				stack[tv.sp * kThreads] = right_first ? cl : cr;
-				tv.sp++;
-				tv.cur = right_first ? cr : cl;
-			} else if (hl) {
-				tv.cur = cl;
-			} else if (hr) {
-				tv.cur = cr;
-			} else {
-				trav_pop<Real, kThreads>(tv, stack);
-			}
-		} else if (RT_POSTPONE && tv.cur != kDone && tv.pending == 0) {
-			tv.pending = tv.cur;
-			trav_pop<Real, kThreads>(tv, stack);
+__device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, int* stack, Tally& tally, Regions& rg,
+                                           int32_t inner_exit = 0) {
+	const int32_t entered = (int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit;
+	while (tv.cur >= 0) {
+		if ((int32_t)__popcll(__ballot(1)) * 16 < entered) break;  // the rest wait at leaves: serve them first
+		region_tick<kCount>(rg, kRegInner);
+		const Node<Real>& n = nodes[tv.cur];
+		Real el, er;
+		bool hl = hit_box<Real>(n.box, r, tv.best_t, &el);
+		bool hr = hit_box<Real>(n.box + 6, r, tv.best_t, &er);
+		int32_t cl = n.child[0], cr = n.child[1];
+		if (kCount) tally.box += 2;
+		if (hl && hr) {
+			bool right_first = er < el;  // nearer child first, the left one on equal entry
+			stack[tv.sp * kThreads] = right_first ? cl : cr;
+			tv.sp++;
+			tv.cur = right_first ? cr : cl;
+		} else if (hl) {
+			tv.cur = cl;
+		} else if (hr) {
+			tv.cur = cr;
 		} else {
-			break;
+			trav_pop<Real, kThreads>(tv, stack);
 		}
 	}
 }
-// Tests the primitives of the postponed leaf and of the leaf in tv.cur (either may be absent)
-// as one run of spheres and one run of cubes, then pops.
+// Tests the primitives of the leaf in tv.cur (the caller guarantees a leaf code) as one run of
+// spheres and one run of cubes, then pops.
 template <typename Real, int kThreads, bool kCount>
 __device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, const Gate<Real>* gates, int* stack, Tally& tally, Regions& rg) {
 	region_tick<kCount>(rg, kRegLeaf);
-	const bool cur_is_leaf = tv.cur != kDone;  // the caller guarantees tv.cur < 0
-	uint32_t ca = tv.pending != 0 ? ~(uint32_t)tv.pending : 0u;  // code 0 = leaf of nothing
-	uint32_t cb = cur_is_leaf ? ~(uint32_t)tv.cur : 0u;
-	int32_t fa = (int32_t)(ca >> 6), nsa = (int32_t)((ca >> 3) & 7u), nca = (int32_t)(ca & 7u);
-	int32_t fb = (int32_t)(cb >> 6), nsb = (int32_t)((cb >> 3) & 7u), ncb = (int32_t)(cb & 7u);
+	const uint32_t code = ~(uint32_t)tv.cur;
+	const int32_t first = (int32_t)(code >> 6), ns = (int32_t)((code >> 3) & 7u), nc = (int32_t)(code & 7u);
 	auto better = [&](Real t, int32_t i) {
 		return t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && prims[i].rank > prims[tv.best_prim].rank));
 	};
-	for (int32_t k = 0; k < nsa + nsb; k++) {
-		int32_t i = k < nsa ? fa + k : fb + (k - nsa);
+	for (int32_t k = 0; k < ns; k++) {
+		int32_t i = first + k;
 		Real t;
 		region_tick<kCount>(rg, kRegSphere);
 		if (kCount) tally.sphere++;
@@ -478,15 +472,14 @@ __device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r
 			if (reachable) { tv.best_t = t; tv.best_prim = i; }
 		}
 	}
-	for (int32_t k = 0; k < nca + ncb; k++) {
-		int32_t i = k < nca ? fa + nsa + k : fb + nsb + (k - nca);
+	for (int32_t k = 0; k < nc; k++) {
+		int32_t i = first + ns + k;
 		Real t;
 		region_tick<kCount>(rg, kRegCube);
 		if (kCount) tally.cube++;
 		if (hit_cube<Real>(prims[i], r, &t) && better(t, i)) { tv.best_t = t; tv.best_prim = i; }
 	}
-	tv.pending = 0;
-	if (cur_is_leaf) trav_pop<Real, kThreads>(tv, stack);
+	trav_pop<Real, kThreads>(tv, stack);
 }
 
 // BVH::trace, src/bvh.rs:130-142, with get_normal of src/shapes/sphere.rs:60-62 and
@@ -529,39 +522,43 @@ RT_FN Real reflectance(Real cosine, Real ref_idx) {
 	Real x2 = x * x;
 	return r0 + (Real(1) - r0) * ((x2 * x2) * x);
 }
-// Material::scatter, src/materials.rs:17-68.  Returns false for None (an absorbed metal ray).
+template <typename Real> struct Scattered {
+	V3<Real> att, dir;
+	bool ok;
+};
+// Material::scatter, src/materials.rs:17-68.  ok = false for None (an absorbed metal ray).
 // Draw counts: Lambertian 3, Metal 3 (also when fuzz is 0), Dielectric 1 unless total
 // internal reflection (the `||` of :54-55 short-circuits).
-RT_FN bool scatter(const Hit<Real>& h, const Mat<Real>& m, V3<Real> dir_in, Rng& rng, V3<Real>* att, V3<Real>* dir_out) {
+RT_FN Scattered<Real> scatter(const Hit<Real>& h, const Mat<Real>& m, V3<Real> dir_in, Rng& rng) {
+	Scattered<Real> out;
+	out.ok = true;
 	if (h.material == RTHIP_LAMBERTIAN) {
 		V3<Real> sd = h.n + random_unit_vector<Real>(rng);
 		const Real tol = Real(0.00000001);
 		if (Fp<Real>::fabs(sd.x) <= tol && Fp<Real>::fabs(sd.y) <= tol && Fp<Real>::fabs(sd.z) <= tol) sd = h.n;
-		*att = ld3(m.albedo);
-		*dir_out = sd;
-		return true;
-	}
-	if (h.material == RTHIP_METAL) {
+		out.att = ld3(m.albedo);
+		out.dir = sd;
+	} else if (h.material == RTHIP_METAL) {
 		V3<Real> reflected = reflect(normalize(dir_in), h.n);
 		V3<Real> sd = reflected + m.param * random_unit_vector<Real>(rng);
-		if (dot(sd, h.n) <= Real(0)) return false;
-		*att = ld3(m.albedo);
-		*dir_out = sd;
-		return true;
-	}
-	Real ir = m.param;
-	Real ratio = h.front ? Fp<Real>::rcp(ir) : ir;
-	V3<Real> unit_dir = normalize(dir_in);
-	Real cos_theta = Fp<Real>::fmin(dot(-unit_dir, h.n), Real(1));
-	Real sin_theta = Fp<Real>::sqrt(Real(1) - (cos_theta * cos_theta));
-	bool cannot_refract = ratio * sin_theta > Real(1);
-	if (cannot_refract || (reflectance<Real>(cos_theta, ratio) > random_range<Real>(Real(0), Real(1), rng))) {
-		*dir_out = reflect(unit_dir, h.n);
+		out.ok = !(dot(sd, h.n) <= Real(0));
+		out.att = ld3(m.albedo);
+		out.dir = sd;
 	} else {
-		*dir_out = refract(unit_dir, h.n, ratio);
+		Real ir = m.param;
+		Real ratio = h.front ? Fp<Real>::rcp(ir) : ir;
+		V3<Real> unit_dir = normalize(dir_in);
+		Real cos_theta = Fp<Real>::fmin(dot(-unit_dir, h.n), Real(1));
+		Real sin_theta = Fp<Real>::sqrt(Real(1) - (cos_theta * cos_theta));
+		bool cannot_refract = ratio * sin_theta > Real(1);
+		if (cannot_refract || (reflectance<Real>(cos_theta, ratio) > random_range<Real>(Real(0), Real(1), rng))) {
+			out.dir = reflect(unit_dir, h.n);
+		} else {
+			out.dir = refract(unit_dir, h.n, ratio);
+		}
+		out.att = mk<Real>(Real(1), Real(1), Real(1));
 	}
-	*att = mk<Real>(Real(1), Real(1), Real(1));
-	return true;
+	return out;
 }
 
 // sqrt(radiance) -> fixed point (2^-36 units).  NaN and negatives count as 0; one sample is
@@ -602,14 +599,14 @@ RT_FN bool shade_ray(const TravRay<Real>& ray, Real best_t, int32_t best_prim, c
 	const Prim<Real>& pr = prims[best_prim];
 	Hit<Real> h = make_hit<Real>(pr, ((pr.id >> kKindShift) & 1) == RTHIP_SPHERE, ray, best_t);
 	const Mat<Real>& mat = mats[h.id];
-	V3<Real> att, nd;
-	if (!scatter<Real>(h, mat, ray.d, rng, &att, &nd)) return false;
+	Scattered<Real> sc = scatter<Real>(h, mat, ray.d, rng);
+	if (!sc.ok) return false;
 	if (h.material == RTHIP_LAMBERTIAN) L = L + T * (ld3(mat.albedo) * mat.param);  // materials.rs:71-77
-	T = T * att;
+	T = T * sc.att;
 	depth--;
 	if (depth <= 0) return false;
 	next->o = h.p;
-	next->d = nd;
+	next->d = sc.dir;
 	return true;
 }
 // raytracer_headless/src/main.rs:53: gamma (sqrt) per sample, then summed.  The buffer is
@@ -678,10 +675,11 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	Tally tally{0, 0, 0};
 	Regions rg{};
 	uint32_t n_rays = 0, n_paths = 0;
-	tv.cur = kDone; tv.pending = 0; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
+	tv.cur = kDone; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
 	rng.state = 0; rng.inc = 1;
 	T = L = mk<Real>(0, 0, 0);
 	ray.o = ray.d = ray.inv = ray.noi = T; ray.eps = ray.rcp_a = 0;
+	ray.inv_xy = ray.noi_xy = ray.inv_zz = ray.noi_zz = f2{0.0f, 0.0f};
 
 	// wave state (uniform)
 	uint32_t item = 0, pool_pos = 0, pool_end = 0;
@@ -744,8 +742,8 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			}
 			if (state == kTraverse) {
 				region_tick<kCount>(rg, kRegTravRound);
-				trav_inner<Real, kThreads, kCount>(tv, ray, nodes, stack, tally, rg);
-				if (tv.cur != kDone || tv.pending != 0) trav_leaf<Real, kThreads, kCount>(tv, ray, prims, gates, stack, tally, rg);
+				trav_inner<Real, kThreads, kCount>(tv, ray, nodes, stack, tally, rg, A.inner_exit);
+				if (tv.cur < 0 && tv.cur != kDone) trav_leaf<Real, kThreads, kCount>(tv, ray, prims, gates, stack, tally, rg);
 				if (tv.cur == kDone) state = kShade;
 			}
 		}
@@ -803,9 +801,9 @@ __global__ __launch_bounds__(kProbeBlock) void probe_kernel(ProbeArgs<Real> A) {
 	trav_begin<Real>(tv);
 	Tally tally{0, 0, 0};
 	Regions rg{};
-	while (tv.cur != kDone || tv.pending != 0) {
+	while (tv.cur != kDone) {
 		trav_inner<Real, kProbeBlock, false>(tv, ray, nodes, stack, tally, rg);
-		if (tv.cur != kDone || tv.pending != 0) trav_leaf<Real, kProbeBlock, false>(tv, ray, prims, gates, stack, tally, rg);
+		if (tv.cur != kDone) trav_leaf<Real, kProbeBlock, false>(tv, ray, prims, gates, stack, tally, rg);
 	}
 	if (tv.best_prim < 0) {
 		A.id[i] = -1; A.t[i] = 0.0; A.front[i] = 0;

@@ -25,9 +25,14 @@ constexpr int kMaxObjects = 1 << 25;  // leaf code holds the first primitive in 
 // child >= 0: index of an inner node.  child < 0: leaf, ~child = first_prim << 6 | n_spheres << 3 | n_cubes.
 constexpr int32_t leaf_code(int32_t first, int32_t ns, int32_t nc) { return ~((first << 6) | (ns << 3) | nc); }
 
+// Plane order inside one child box of a Node: (lo.x, lo.y), (hi.x, hi.y), (lo.z, hi.z).  The f32
+// box test multiplies the first two pairs by (1/d.x, 1/d.y) and the third by (1/d.z, 1/d.z) with
+// packed two-wide FMAs, so each pair sits in one aligned 8-byte slot.
+constexpr int kBoxLoX = 0, kBoxLoY = 1, kBoxHiX = 2, kBoxHiY = 3, kBoxLoZ = 4, kBoxHiZ = 5;
+
 template <typename Real>
 struct alignas(sizeof(Real) * 16) Node {
-	Real box[12];      // left child lo.xyz hi.xyz, right child lo.xyz hi.xyz
+	Real box[12];      // per child (left, then right) six planes in the order of kBox* above
 	int32_t child[2];  // left, right
 };
 static_assert(sizeof(Node<float>) == 64, "f32 node is one 64-byte line");

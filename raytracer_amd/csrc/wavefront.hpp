@@ -159,8 +159,9 @@ __global__ __launch_bounds__(kThreads) void wf_extend(WfArgs<Real> A) {
 	Trav<Real> tv;
 	Tally tally{0, 0, 0};
 	Regions rg{};
-	tv.cur = kDone; tv.pending = 0; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
+	tv.cur = kDone; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
 	ray.o = ray.d = ray.inv = ray.noi = mk<Real>(0, 0, 0); ray.eps = ray.rcp_a = 0;
+	ray.inv_xy = ray.noi_xy = ray.inv_zz = ray.noi_zz = f2{0.0f, 0.0f};
 	uint32_t pool_pos = 0, pool_end = 0;
 	bool dry = false;
 
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void wf_extend(WfArgs<Real> A) {
 		if (__ballot(busy) == 0ull) break;
 		if (busy) {
 			trav_inner<Real, kThreads, false>(tv, ray, nodes, stack, tally, rg);
-			if (tv.cur != kDone || tv.pending != 0) trav_leaf<Real, kThreads, false>(tv, ray, prims, gates, stack, tally, rg);
+			if (tv.cur != kDone) trav_leaf<Real, kThreads, false>(tv, ray, prims, gates, stack, tally, rg);
 			if (tv.cur == kDone) {
 				A.hit_t[index] = tv.best_t;
 				A.hit_prim[index] = tv.best_prim;
