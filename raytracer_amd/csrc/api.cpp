@@ -138,8 +138,9 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// amortise it.
 	int forced = env_int("RTHIP_THREADS", 0);
 	int best_waves = -1, bpc = 0;
-	for (int threads : {256, 512}) {
+	for (int threads : {256, 512, 1024}) {
 		if (forced && threads != forced) continue;
+		if (threads == 1024 && (wavefront || forced != 1024)) continue;  // 32 waves per CU at 64 VGPRs measured no faster than 24 at 80: on request only
 		size_t lds = (size_t)c->tree_depth * threads * 4 + (in_lds ? blob.lds_bytes : 0);
 		int b = 0;
 		if (wavefront) HIP_TRY(c, f64 ? wf_extend_blocks_per_cu_f64(threads, in_lds, lds, &b) : wf_extend_blocks_per_cu_f32(threads, in_lds, lds, &b));

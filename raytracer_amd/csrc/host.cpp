@@ -483,8 +483,9 @@ struct Builder {
 				} else {
 					for (int q = 0; q < 3; q++) {
 						p64.v[3 + q] = o.extent[q];
-						p32.v[q] = (float)(o.center[q] - o.extent[q]);
-						p32.v[3 + q] = (float)(o.center[q] + o.extent[q]);
+						static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+						p32.v[lo_slot[q]] = (float)(o.center[q] - o.extent[q]);
+						p32.v[hi_slot[q]] = (float)(o.center[q] + o.extent[q]);
 					}
 				}
 				p64.id = p32.id = id | (o.material << kMatShift) | (o.kind << kKindShift);

@@ -296,13 +296,16 @@ RT_FN bool hit_sphere(const Prim<Real>& s, const TravRay<Real>& r, Real* t) {
 // a negative half extent never hits.  f64: the reference's centre/half-extent form.  f32: the
 // same planes stored as lo = c - he, hi = c + he (rounded once from f64): per axis the near
 // plane is lo when d >= 0 else hi, which is -n - k of the reference in exact arithmetic,
-// without the cancellation of (o - c) against he for slabs of half extent 1e3..1e5.
+// without the cancellation of (o - c) against he for slabs of half extent 1e3..1e5.  The
+// separately rounded (plane - o) * inv keeps t accurate to an ulp far from the origin, which
+// the fused plane * inv - o * inv of the box test does not (measured: the fused form is also
+// no faster here).
 RT_FN bool hit_cube(const Prim<Real>& c, const TravRay<Real>& r, Real* t) {
 	Real t_n, t_f;
 	if constexpr (std::is_same<Real, float>::value) {
-		float ax = (c.v[0] - r.o.x) * r.inv.x, bx = (c.v[3] - r.o.x) * r.inv.x;
-		float ay = (c.v[1] - r.o.y) * r.inv.y, by = (c.v[4] - r.o.y) * r.inv.y;
-		float az = (c.v[2] - r.o.z) * r.inv.z, bz = (c.v[5] - r.o.z) * r.inv.z;
+		float ax = (c.v[kBoxLoX] - r.o.x) * r.inv.x, bx = (c.v[kBoxHiX] - r.o.x) * r.inv.x;
+		float ay = (c.v[kBoxLoY] - r.o.y) * r.inv.y, by = (c.v[kBoxHiY] - r.o.y) * r.inv.y;
+		float az = (c.v[kBoxLoZ] - r.o.z) * r.inv.z, bz = (c.v[kBoxHiZ] - r.o.z) * r.inv.z;
 		bool nx = r.inv.x < 0.0f, ny = r.inv.y < 0.0f, nz = r.inv.z < 0.0f;
 		t_n = Fp<float>::fmax(Fp<float>::fmax(nx ? bx : ax, ny ? by : ay), nz ? bz : az);
 		t_f = Fp<float>::fmin(Fp<float>::fmin(nx ? ax : bx, ny ? ay : by), nz ? az : bz);
@@ -498,7 +501,8 @@ RT_FN Hit<Real> make_hit(const Prim<Real>& pr, bool is_sphere, const TravRay<Rea
 		else h.n = (h.p - ld3(pr.v)) / pr.v[3];
 	} else {
 		V3<Real> centre;
-		if constexpr (std::is_same<Real, float>::value) centre = (ld3(pr.v) + ld3(pr.v + 3)) * 0.5f;
+		if constexpr (std::is_same<Real, float>::value)
+			centre = mk<Real>(pr.v[kBoxLoX] + pr.v[kBoxHiX], pr.v[kBoxLoY] + pr.v[kBoxHiY], pr.v[kBoxLoZ] + pr.v[kBoxHiZ]) * 0.5f;
 		else centre = ld3(pr.v);
 		V3<Real> rel = h.p - centre;
 		Real ax = Fp<Real>::fabs(rel.x), ay = Fp<Real>::fabs(rel.y), az = Fp<Real>::fabs(rel.z);
@@ -639,7 +643,7 @@ enum : int { kIdle = 0, kTraverse = 1, kShade = 2 };
 // The megakernel.
 // ---------------------------------------------------------------------------------------
 template <typename Real, int kThreads, bool kLds, bool kCount>
-__global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? RT_MINWAVES : 2)) void render_kernel(RenderArgs<Real> A) {
+__global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? (kThreads == 1024 ? 8 : RT_MINWAVES) : 2)) void render_kernel(RenderArgs<Real> A) {
 	extern __shared__ __align__(64) char smem[];
 	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kThreads]
 	const uint32_t stack_bytes = (uint32_t)A.stack_entries * kThreads * 4u;

@@ -40,8 +40,9 @@ static_assert(sizeof(Node<double>) == 128, "f64 node is 128 bytes");
 
 // Sphere: v = centre.xyz, radius, gate word (see Gate), 0.
 // Cube, f64: v = centre.xyz, half_extent.xyz (the reference's own representation).
-// Cube, f32: v = lo.xyz, hi.xyz, computed in f64 as centre -/+ half_extent and rounded once,
-//            so that huge cubes (ground slabs of half extent 1e5) keep exact faces.
+// Cube, f32: v = the six face planes in the order of kBox* (like a node's child box), computed
+//            in f64 as centre -/+ half_extent and rounded once, so that huge cubes (ground slabs
+//            of half extent 1e5) keep exact faces.
 template <typename Real>
 struct alignas(sizeof(Real) * 8) Prim {
 	Real v[6];

@@ -6,9 +6,13 @@ import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 name, vals = sys.argv[1], sys.argv[2:]
 for which, scene, depth in (("cfg2", "default", 10), ("cfg3", "sample", 50)):
-    r = rt.Renderer(rt.Scene.generate(scene), rt.Camera(*CAM, 1920, 1080), max_depth=depth, seed=1)
+    r = None
     for v in vals:
         os.environ[name] = v
+        if r is None or name.startswith(("RTHIP_SAH", "RTHIP_TREE")):  # read at scene upload
+            if r is not None:
+                r.close()
+            r = rt.Renderer(rt.Scene.generate(scene), rt.Camera(*CAM, 1920, 1080), max_depth=depth, seed=1)
         best = 0.0
         for _ in range(4):
             r.reset_accumulation(); r.accumulate(32, spp_begin=0); s = r.stats()
