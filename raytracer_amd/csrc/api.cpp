@@ -185,6 +185,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.sky_mode = p->sky_mode; a.part_index = p->part_index; a.part_count = p->part_count;
 	a.n_items = plan.n_items; a.chunk = plan.chunk; a.n_chunks = plan.n_chunks; a.trav_threshold = plan.threshold;
 	a.inner_exit = env_int("RTHIP_INNER_EXIT", 5);
+	a.regen_min = std::max(1, std::min(64, env_int("RTHIP_REGEN_MIN", 16)));
 	a.accum = accum; a.samples_out = samples_out;
 	a.queue = reinterpret_cast<uint32_t*>(c->d_control);
 	a.stats = reinterpret_cast<unsigned long long*>(c->d_control + 8);

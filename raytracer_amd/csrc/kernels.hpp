@@ -59,6 +59,7 @@ struct RenderArgs {
 	int32_t part_index, part_count;
 	uint32_t n_items, chunk, n_chunks;
 	int32_t trav_threshold;
+	int32_t regen_min;      // regenerate paths only when at least this many lanes are idle (or all are)
 	int32_t inner_exit;     // sixteenths: leave the inner-node loop when fewer lanes than this share of the round remain in it
 	unsigned long long* accum;    // [tiles][3 channels][64 px] fixed point
 	Real* samples_out;            // optional [spp_count][H][W][3]
@@ -695,6 +696,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 		for (;;) {
 			unsigned long long need = __ballot(state == kIdle);
 			if (need == 0ull) break;
+			if ((int32_t)__popcll(need) < A.regen_min && need != ~0ull) break;  // wait for more idle lanes: camera rays for few lanes waste the wave
 			if (pool_pos == pool_end) {
 				if (queue_dry) break;
 				uint32_t it = 0;
@@ -741,8 +743,10 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			if (m == 0ull) break;
 			uint32_t n_trav = (uint32_t)__popcll(m);
 			if ((int32_t)n_trav <= A.trav_threshold) {
-				unsigned long long waiting = __ballot(state == kShade || (state == kIdle && !queue_dry));
-				if (waiting != 0ull) break;
+				// lanes that shading or regeneration would serve right now (idle lanes only count once
+				// there are enough of them for regeneration to accept, so leaving here always makes progress)
+				const bool refill = !queue_dry && (int32_t)__popcll(__ballot(state == kIdle)) >= A.regen_min;
+				if (refill || __ballot(state == kShade) != 0ull) break;
 			}
 			if (state == kTraverse) {
 				region_tick<kCount>(rg, kRegTravRound);
