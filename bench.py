@@ -186,13 +186,20 @@ def main():
             achieved = flops_per_launch / (res["kernel_ms"] * 1e-3) / 1e12
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(args.workload)
+            if os.path.exists(tpath):  # measured with rocprofv3 counters (bytes per path), scaled to this launch
+                t = json.load(open(tpath)).get(args.workload)
+                traffic = t["hbm_bytes_per_path"] * res["paths"] if t else None
             line["roofline"] = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                                 "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "kernel": "render_kernel<float>",
                                 "kernel_ms": res["kernel_ms"], "algorithmic_flop_per_path": work["flop_per_path"],
                                 "algorithmic_bytes_per_path": work["bytes_per_path"], "box_tests_per_ray": work["box_tests_per_ray"],
                                 "prim_tests_per_ray": work["prim_tests_per_ray"]}
+            # the same launch against the memory roof: what the algorithm must move through HBM is one
+            # read-modify-write of the accumulation words of every pixel (scene and ray state stay on chip)
+            hbm_alg = wl["width"] * wl["height"] * 3 * 8 * 2
+            gbs = hbm_alg / (res["kernel_ms"] * 1e-3) / 1e9
+            line["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
+                                    "note": "not the binding roof: the kernel is VALU-issue bound"}
         if baseline:
             line["cpu_baseline"] = baseline
             line["speedup_vs_cpu"] = value / baseline["value"]
