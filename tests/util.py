@@ -36,3 +36,48 @@ def pack_accum_words(img, width, height):
     full = np.zeros((tiles_y * 8, tiles_x * 8, 3), dtype=np.uint64)
     full[:height, :width] = np.floor(np.asarray(img) * 2.0 ** 36 + 0.5).astype(np.uint64)
     return full.reshape(tiles_y, 8, tiles_x, 8, 3).transpose(0, 2, 4, 1, 3).reshape(-1).copy()
+
+
+def random_scene(rt, seed):
+    """A small adversarial scene for differential tests: spheres and cubes of all three
+    materials, with the cases that make traversal order matter: concentric glass shells (negative
+    radius), stand-alone inverted spheres, cubes with coplanar faces and shared centres, flat and
+    zero-size cubes, negative half extents, objects around and behind the camera."""
+    g = np.random.default_rng(seed)
+    s = rt.Scene()
+
+    def material():
+        k = g.integers(0, 3)
+        if k == 0:
+            return rt.Material.lambertian(tuple(g.uniform(0.1, 0.9, 3)), float(g.choice([0.0, 0.0, 2.0])))
+        if k == 1:
+            return rt.Material.metal(tuple(g.uniform(0.5, 1.0, 3)), float(g.choice([0.0, 0.2])))
+        return rt.Material.dielectric(1.5)
+
+    n = int(g.integers(6, 60))
+    grid = g.integers(0, 2) == 1  # snap centres and sizes to a coarse grid: exact ties
+    for _ in range(n):
+        c = g.uniform(-4, 4, 3)
+        if grid:
+            c = np.round(c * 2) / 2
+        kind = g.integers(0, 10)
+        if kind < 4:
+            r = float(g.choice([0.25, 0.5, 1.0])) if grid else float(g.uniform(0.1, 1.2))
+            s.add_sphere(tuple(c), r, material())
+            if g.random() < 0.3:   # hollow shell, src/scene.rs:149
+                s.add_sphere(tuple(c), -0.9 * r, rt.Material.dielectric(1.5))
+        elif kind == 4:
+            s.add_sphere(tuple(c), -float(g.uniform(0.2, 1.0)), material())
+        else:
+            he = g.choice([0.25, 0.5, 1.0], 3) if grid else g.uniform(0.05, 1.0, 3)
+            if g.random() < 0.1:
+                he[g.integers(0, 3)] = 0.0
+            if g.random() < 0.05:
+                he = -he
+            s.add_cube(tuple(c), tuple(he), material())
+    if g.random() < 0.7:
+        s.add_cube((0.0, -5.0 - 100.0, 0.0), (100.0, 100.0, 100.0), rt.Material.lambertian((0.5, 0.5, 0.5), 0.0))
+    origin = tuple(g.uniform(-6, 6, 3))
+    direction = tuple(-np.asarray(origin) + g.uniform(-1, 1, 3))
+    cam = (origin, direction, float(g.uniform(30, 90)), float(g.uniform(2, 10)), float(g.choice([0.0, 0.6])))
+    return s, cam
