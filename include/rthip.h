@@ -133,6 +133,12 @@ int32_t rthip_accum_buffer(rthip_ctx* ctx, void** device_ptr, uint64_t* n_words)
 /* Use caller-owned device memory of n_words uint64 (e.g. a torch tensor, so that it can be
  * handed to an RCCL collective) as the accumulation buffer; NULL returns to the own buffer. */
 int32_t rthip_set_accum_buffer(rthip_ctx* ctx, void* device_ptr, uint64_t n_words);
+/* Checkpoint / resume of a long render: copy the accumulation words (layout above) to host
+ * memory and back.  Sums are integers, so a render resumed from a checkpoint ends bit-identical
+ * to an uninterrupted one.  (No counterpart in the reference, whose `output` Vec lives and dies
+ * with the process, raytracer_headless/src/main.rs:34-57; its callers can only restart.) */
+int32_t rthip_accum_download(rthip_ctx* ctx, uint64_t* words, uint64_t n_words);
+int32_t rthip_accum_upload(rthip_ctx* ctx, const uint64_t* words, uint64_t n_words);
 
 /* Read back sum_s sqrt(sample) per channel, row-major [height][width][3] (the Vec<Vec3>
  * `output` of raytracer_headless/src/main.rs:34 before the division of :55). */

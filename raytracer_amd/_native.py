@@ -58,6 +58,8 @@ SYMBOLS = {
     "rthip_reset_accumulation": (C.c_int32, [_P]),
     "rthip_accum_buffer": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "rthip_set_accum_buffer": (C.c_int32, [_P, _P, C.c_uint64]),
+    "rthip_accum_download": (C.c_int32, [_P, _P, C.c_uint64]),
+    "rthip_accum_upload": (C.c_int32, [_P, _P, C.c_uint64]),
     "rthip_read_accum": (C.c_int32, [_P, _P]),
     "rthip_read_rgb8": (C.c_int32, [_P, C.c_uint32, _P]),
     "rthip_read_xrgb32": (C.c_int32, [_P, C.c_uint32, _P]),

@@ -237,6 +237,26 @@ class Renderer:
     def set_accum_buffer(self, device_ptr, n_words):
         self._check(self._lib.rthip_set_accum_buffer(self._ctx, C.c_void_p(device_ptr), n_words))
 
+    def save_checkpoint(self, path):
+        """Writes the accumulation words and the sample count to an .npz file; load_checkpoint on a
+        renderer of the same scene, camera and seed resumes the render where it stopped (sums are
+        integers, so the resumed image is bit-identical to an uninterrupted one)."""
+        _, n = self.accum_buffer()
+        words = np.zeros(n, dtype=np.uint64)
+        self._check(self._lib.rthip_accum_download(self._ctx, words.ctypes.data, n))
+        np.savez_compressed(path, words=words, spp_done=np.int64(self.spp_done), seed=np.int64(self.seed),
+                            width=np.int64(self.camera.width), height=np.int64(self.camera.height))
+
+    def load_checkpoint(self, path):
+        with np.load(path) as z:
+            if int(z["width"]) != self.camera.width or int(z["height"]) != self.camera.height:
+                raise ValueError("checkpoint is for a %dx%d frame" % (int(z["width"]), int(z["height"])))
+            if int(z["seed"]) != self.seed:
+                raise ValueError("checkpoint was rendered with another seed: its samples would repeat or be skipped")
+            words = np.ascontiguousarray(z["words"], dtype=np.uint64)
+            self._check(self._lib.rthip_accum_upload(self._ctx, words.ctypes.data, len(words)))
+            self.spp_done = int(z["spp_done"])
+
     def read_accum(self):
         """sum_s sqrt(sample), float64 [H, W, 3]."""
         out = np.zeros((self.camera.height, self.camera.width, 3), dtype=np.float64)

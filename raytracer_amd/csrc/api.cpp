@@ -49,6 +49,8 @@ struct rthip_ctx {
 	// wavefront variant: ping-pong path state, hit records and the per-bounce counter block
 	char* wf_mem = nullptr;
 	size_t wf_bytes = 0;
+	void* readback = nullptr;  // device staging of the read-back calls
+	size_t readback_bytes = 0;
 	uint32_t* wf_counters = nullptr;  // kWfMaxDepth + 1 queue sizes, then kWfMaxDepth work counters
 	rthip_stats stats{};
 	bool launch_pending = false;
@@ -354,6 +356,7 @@ void rthip_destroy(rthip_ctx* c) {
 	if (c->own_accum) (void)hipFree(c->own_accum);
 	if (c->d_control) (void)hipFree(c->d_control);
 	if (c->wf_mem) (void)hipFree(c->wf_mem);
+	if (c->readback) (void)hipFree(c->readback);
 	if (c->wf_counters) (void)hipFree(c->wf_counters);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -486,6 +489,31 @@ int32_t rthip_set_accum_buffer(rthip_ctx* c, void* device_ptr, uint64_t n_words)
 	return RTHIP_OK;
 }
 
+static int32_t accum_copy(rthip_ctx* c, void* host, uint64_t n_words, bool to_host) {
+	if (!c || !host) return RTHIP_ERR_INVALID;
+	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+	HIP_TRY(c, hipSetDevice(c->device));
+	int32_t rc = ensure_accum(c);
+	if (rc != RTHIP_OK) return rc;
+	if (n_words != c->accum_words) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer holds tiles_x*tiles_y*192 words");
+	if (to_host) HIP_TRY(c, hipMemcpyAsync(host, c->accum, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+	else HIP_TRY(c, hipMemcpyAsync(c->accum, host, n_words * 8, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return RTHIP_OK;
+}
+int32_t rthip_accum_download(rthip_ctx* c, uint64_t* words, uint64_t n_words) { return accum_copy(c, words, n_words, true); }
+int32_t rthip_accum_upload(rthip_ctx* c, const uint64_t* words, uint64_t n_words) { return accum_copy(c, const_cast<uint64_t*>(words), n_words, false); }
+
+// Device staging for the read-back calls: kept between calls (a viewer reads a frame every few
+// milliseconds), grown on demand, freed with the context.
+static int32_t ensure_readback(rthip_ctx* c, size_t bytes) {
+	if (c->readback_bytes >= bytes) return RTHIP_OK;
+	if (c->readback) { HIP_TRY(c, hipFree(c->readback)); c->readback = nullptr; c->readback_bytes = 0; }
+	HIP_TRY(c, hipMalloc(&c->readback, bytes));
+	c->readback_bytes = bytes;
+	return RTHIP_OK;
+}
+
 int32_t rthip_read_accum(rthip_ctx* c, double* rgb) {
 	if (!c || !rgb) return RTHIP_ERR_INVALID;
 	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
@@ -493,13 +521,12 @@ int32_t rthip_read_accum(rthip_ctx* c, double* rgb) {
 	int32_t rc = ensure_accum(c);
 	if (rc != RTHIP_OK) return rc;
 	size_t n = (size_t)c->cam.width * c->cam.height * 3;
-	double* d = nullptr;
-	HIP_TRY(c, hipMalloc(&d, n * sizeof(double)));
-	hipError_t e = launch_unpack(c->accum, d, c->cam.width, c->cam.height, c->tiles_x, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(rgb, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	(void)hipFree(d);
-	HIP_TRY(c, e);
+	rc = ensure_readback(c, n * sizeof(double));
+	if (rc != RTHIP_OK) return rc;
+	double* d = static_cast<double*>(c->readback);
+	HIP_TRY(c, launch_unpack(c->accum, d, c->cam.width, c->cam.height, c->tiles_x, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(rgb, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return RTHIP_OK;
 }
 
@@ -511,13 +538,11 @@ static int32_t read_quantized(rthip_ctx* c, uint32_t spp_total, void* out, int x
 	int32_t rc = ensure_accum(c);
 	if (rc != RTHIP_OK) return rc;
 	size_t bytes = (size_t)c->cam.width * c->cam.height * (xrgb ? 4 : 3);
-	void* d = nullptr;
-	HIP_TRY(c, hipMalloc(&d, bytes));
-	hipError_t e = launch_finalize(c->accum, d, c->cam.width, c->cam.height, c->tiles_x, spp_total, xrgb, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	(void)hipFree(d);
-	HIP_TRY(c, e);
+	rc = ensure_readback(c, bytes);
+	if (rc != RTHIP_OK) return rc;
+	HIP_TRY(c, launch_finalize(c->accum, c->readback, c->cam.width, c->cam.height, c->tiles_x, spp_total, xrgb, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(out, c->readback, bytes, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return RTHIP_OK;
 }
 int32_t rthip_read_rgb8(rthip_ctx* c, uint32_t spp_total, uint8_t* rgb) { return read_quantized(c, spp_total, rgb, 0); }

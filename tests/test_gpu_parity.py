@@ -367,3 +367,29 @@ def test_random_scenes_f64_bit_exact_f32_close(rt, oracle, variant):
         g32 = r.trace_primary(rt.F32, jitter=True, sample=2)
         assert (g32[0] != ref[0]).mean() <= 5e-3, seed
         r.close()
+
+
+def test_checkpoint_resume_is_bit_identical(rt, renderers, tmp_path):
+    w, h = 200, 120
+    r, sc = renderers("default", w, h, seed=31)
+    r.precision = rt.F32
+    r.reset_accumulation(); r.accumulate(5)
+    whole = r.read_accum()
+    r.reset_accumulation(); r.accumulate(2)
+    path = str(tmp_path / "ckpt.npz")
+    r.save_checkpoint(path)
+    r2 = rt.Renderer(sc, rt.Camera(*camera_args("default", w, h, rt)), seed=31)   # a new process would do the same
+    r2.load_checkpoint(path)
+    assert r2.spp_done == 2
+    r2.accumulate(3)
+    assert np.array_equal(r2.read_accum(), whole)
+    assert np.array_equal(r2.read_rgb8(), _quantize_like_reference(whole / 5))
+    other = rt.Renderer(sc, rt.Camera(*camera_args("default", w, h, rt)), seed=32)
+    with pytest.raises(ValueError):
+        other.load_checkpoint(path)
+    r2.close(); other.close()
+
+
+def _quantize_like_reference(v):   # raytracer_headless/src/main.rs:6-12: (v * 255.0) as u8
+    x = np.nan_to_num(v * 255.0, nan=0.0, posinf=255.0, neginf=0.0)
+    return np.clip(np.trunc(x), 0, 255).astype(np.uint8)
