@@ -1,0 +1,69 @@
+"""rt_headless, the C++ counterpart of raytracer_headless with --backend hip."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from util import camera_args
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "raytracer_amd", "rt_headless")
+
+
+def read_png_rgb8(path):
+    """Decoder for what the image crate's RgbImage::save produces in the reference
+    (raytracer_headless/src/main.rs:64-72) and rt_headless writes: 8-bit RGB, non-interlaced."""
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w = 8, b"", None
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(tag + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0], "chunk CRC"
+        if tag == b"IHDR":
+            w, h, depth, colour, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            assert (depth, colour, interlace) == (8, 2, 0)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, w * 3 + 1)
+    assert not raw[:, 0].any(), "filter type none on every row"
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+def test_cli_fails_loudly_without_a_gpu_or_with_bad_arguments():
+    import torch
+    assert os.path.exists(EXE), "run __graft_entry__.build() first"
+    bad = subprocess.run([EXE, "--backend", "cpu"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "only --backend hip" in bad.stderr
+    bad = subprocess.run([EXE, "--backend", "hip", "--bogus"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "usage" in bad.stderr
+    if not torch.cuda.is_available():   # there is no CPU path to fall back to
+        out = subprocess.run([EXE, "--backend", "hip", "--width", "16", "--height", "16", "--spp", "1", "--out", os.devnull],
+                             capture_output=True, text=True)
+        assert out.returncode != 0 and "no HIP device" in out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,sky", [("default", "reference"), ("wallpaper", "wallpaper")])
+def test_cli_png_equals_library_readback(rt, tmp_path, scene, sky):
+    w, h, spp, seed = 96, 54, 6, 77
+    png = str(tmp_path / "out.png")
+    out = subprocess.run([EXE, "--backend", "hip", "--scene", scene, "--width", str(w), "--height", str(h), "--spp", str(spp),
+                          "--seed", str(seed), "--sky", sky, "--chunk-spp", "4", "--out", png], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "Rendering took" in out.stdout   # raytracer_headless/src/main.rs:59-62
+    img = read_png_rgb8(png)
+    cam = camera_args(scene, w, h, rt)
+    if scene == "wallpaper":   # the CLI keeps the headless lens (focus 10, defocus 0.6) for every scene
+        cam = cam[:3] + (10.0, 0.6, w, h)
+    else:                      # raytracer_headless/src/main.rs:22: the direction is normalised before Camera::new
+        n = (13.0 * 13.0 + 1.5 * 1.5 + 3.0 * 3.0) ** 0.5
+        cam = (cam[0], (-(13.0 / n), -(1.5 / n), -(3.0 / n))) + cam[2:]
+    r = rt.Renderer(rt.Scene.generate(scene), rt.Camera(*cam), seed=seed, sky_mode=1 if sky == "wallpaper" else 0)
+    r.accumulate(spp)
+    assert np.array_equal(img, r.read_rgb8())
+    r.close()
