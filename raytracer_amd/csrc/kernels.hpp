@@ -521,7 +521,9 @@ RT_FN Hit<Real> make_hit(const Prim<Real>& pr, bool is_sphere, const TravRay<Rea
 
 // Material::reflectance, src/materials.rs:80-85 (Schlick); (1-cos)^5 as a multiply chain.
 RT_FN Real reflectance(Real cosine, Real ref_idx) {
-	Real r0 = (Real(1) - ref_idx) / (Real(1) + ref_idx);
+	Real r0;
+	if constexpr (std::is_same<Real, float>::value) r0 = (1.0f - ref_idx) * Fp<float>::rcp(1.0f + ref_idx);
+	else r0 = (Real(1) - ref_idx) / (Real(1) + ref_idx);
 	r0 = r0 * r0;
 	Real x = Real(1) - cosine;
 	Real x2 = x * x;
@@ -537,22 +539,25 @@ template <typename Real> struct Scattered {
 RT_FN Scattered<Real> scatter(const Hit<Real>& h, const Mat<Real>& m, V3<Real> dir_in, Rng& rng) {
 	Scattered<Real> out;
 	out.ok = true;
-	if (h.material == RTHIP_LAMBERTIAN) {
-		V3<Real> sd = h.n + random_unit_vector<Real>(rng);
+	const V3<Real> unit_dir = normalize(dir_in);  // metal and glass use it; computed once for the wave
+	if (h.material != RTHIP_DIELECTRIC) {
+		// Lambertian: n + ruv (near-zero -> n).  Metal: reflect(unit_dir, n) + fuzz * ruv, absorbed when it
+		// points into the surface.  Both draw one random unit vector, so the lanes of either kind share one
+		// instruction stream: base + scale * ruv with (n, 1) or (reflected, fuzz); 1 * ruv is exact.
+		const bool metal = h.material == RTHIP_METAL;
+		const V3<Real> ruv = random_unit_vector<Real>(rng);
+		const V3<Real> reflected = reflect(unit_dir, h.n);
+		const V3<Real> base = metal ? reflected : h.n;
+		const Real scale = metal ? m.param : Real(1);
+		V3<Real> sd = base + scale * ruv;
 		const Real tol = Real(0.00000001);
-		if (Fp<Real>::fabs(sd.x) <= tol && Fp<Real>::fabs(sd.y) <= tol && Fp<Real>::fabs(sd.z) <= tol) sd = h.n;
-		out.att = ld3(m.albedo);
-		out.dir = sd;
-	} else if (h.material == RTHIP_METAL) {
-		V3<Real> reflected = reflect(normalize(dir_in), h.n);
-		V3<Real> sd = reflected + m.param * random_unit_vector<Real>(rng);
-		out.ok = !(dot(sd, h.n) <= Real(0));
+		if (!metal && Fp<Real>::fabs(sd.x) <= tol && Fp<Real>::fabs(sd.y) <= tol && Fp<Real>::fabs(sd.z) <= tol) sd = h.n;
+		out.ok = !(metal && dot(sd, h.n) <= Real(0));
 		out.att = ld3(m.albedo);
 		out.dir = sd;
 	} else {
 		Real ir = m.param;
 		Real ratio = h.front ? Fp<Real>::rcp(ir) : ir;
-		V3<Real> unit_dir = normalize(dir_in);
 		Real cos_theta = Fp<Real>::fmin(dot(-unit_dir, h.n), Real(1));
 		Real sin_theta = Fp<Real>::sqrt(Real(1) - (cos_theta * cos_theta));
 		bool cannot_refract = ratio * sin_theta > Real(1);
