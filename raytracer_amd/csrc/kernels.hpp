@@ -643,7 +643,7 @@ __device__ __forceinline__ bool decode_path(uint32_t item, uint32_t j, uint32_t 
 	return out->px < (uint32_t)width && out->py < (uint32_t)height && out->s_local < spp_count;
 }
 
-enum : int { kIdle = 0, kTraverse = 1, kShade = 2 };
+enum : int { kIdle = 0, kTraverse = 1, kShade = 2, kFresh = 3 };
 
 // ---------------------------------------------------------------------------------------
 // The megakernel.
@@ -697,6 +697,24 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	const uint32_t pool_size = 64u * A.chunk;
 
 	for (;;) {
+		// ---- shading ---------------------------------------------------------------------
+		if (state == kShade) {
+			region_tick<kCount>(rg, kRegShade);
+			n_rays++;
+			RayT<Real> next;
+			if (shade_ray<Real>(ray, tv.best_t, tv.best_prim, prims, mats, A.sky_mode, rng, T, L, depth, &next)) {
+				ray.o = next.o; ray.d = next.d;
+				state = kFresh;
+			} else {
+				if (A.samples_out) {
+					Real* so = A.samples_out + (size_t)sample_slot * 3;
+					so[0] = L.x; so[1] = L.y; so[2] = L.z;
+				}
+				accumulate_sample<Real>(A.accum, accum_index, L);
+				state = kIdle;
+			}
+		}
+
 		// ---- regeneration: hand idle lanes the next paths of the wave's pool -------------
 		for (;;) {
 			unsigned long long need = __ballot(state == kIdle);
@@ -728,9 +746,8 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 						n_paths++;
 						region_tick<kCount>(rg, kRegStart);
 						if (depth > 0) {
-							ray = prepare<Real>(r);
-							trav_begin<Real>(tv);
-							state = kTraverse;
+							ray.o = r.o; ray.d = r.d;
+							state = kFresh;
 						} else if (A.samples_out) {  // renderer.rs:10-12: depth <= 0 -> black
 							Real* so = A.samples_out + (size_t)sample_slot * 3;
 							so[0] = so[1] = so[2] = Real(0);
@@ -741,6 +758,12 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			pool_pos += take;
 		}
 		if (__ballot(state != kIdle) == 0ull) break;
+		// rays made above by shading (next bounce) and by regeneration (camera rays) are set up together
+		if (state == kFresh) {
+			ray = prepare<Real>(RayT<Real>{ray.o, ray.d});
+			trav_begin<Real>(tv);
+			state = kTraverse;
+		}
 
 		// ---- traversal: until few lanes are left traversing while others wait -------------
 		for (;;) {
@@ -761,24 +784,6 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			}
 		}
 
-		// ---- shading ---------------------------------------------------------------------
-		if (state == kShade) {
-			region_tick<kCount>(rg, kRegShade);
-			n_rays++;
-			RayT<Real> next;
-			if (shade_ray<Real>(ray, tv.best_t, tv.best_prim, prims, mats, A.sky_mode, rng, T, L, depth, &next)) {
-				ray = prepare<Real>(next);
-				trav_begin<Real>(tv);
-				state = kTraverse;
-			} else {
-				if (A.samples_out) {
-					Real* so = A.samples_out + (size_t)sample_slot * 3;
-					so[0] = L.x; so[1] = L.y; so[2] = L.z;
-				}
-				accumulate_sample<Real>(A.accum, accum_index, L);
-				state = kIdle;
-			}
-		}
 	}
 
 	// ---- statistics: one atomic per wave ------------------------------------------------
