@@ -3,8 +3,8 @@
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torch.distributed.run)
 
 A step = one pass of the hot path: render `spp` samples of every pixel of the workload's frame
-into the accumulation buffer resident in HBM (and, for N > 1, merge the ranks' buffers with one
-RCCL reduce).  Scaling is weak: every GPU renders its own `spp` samples of the full frame, so
+into an accumulation buffer resident in HBM (and, for N > 1, merge the ranks' buffers with one
+RCCL reduce per frame, double-buffered so that it overlaps the next frame's tracing).  Scaling is weak: every GPU renders its own `spp` samples of the full frame, so
 N GPUs deliver an image of N x spp samples in the same time.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -115,17 +115,19 @@ def main():
         r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED)
         stream = torch.cuda.current_stream(device)
         r.set_stream(stream.cuda_stream)
-        accum = D.new_accum_tensor(wl["width"], wl["height"], device)
-        r.set_accum_buffer(accum.data_ptr(), accum.numel())
+        pipe = D.MergePipeline(lambda: D.new_accum_tensor(wl["width"], wl["height"], device), dst=0)
         begin = rank * wl["spp"]  # weak scaling: every rank renders its own samples of the full frame
 
         def step():
+            accum = pipe.acquire()   # the other buffer may still be in its reduce
             accum.zero_()
+            r.set_accum_buffer(accum.data_ptr(), accum.numel())
             r.accumulate(wl["spp"], spp_begin=begin, sync=False)
-            D.merge_accum(accum, dst=0)
+            pipe.release()           # one RCCL reduce per frame, overlapped with the next frame's tracing
 
         for _ in range(warmup):
             step()
+        pipe.drain()
         kernel_ms = []
         rays = paths = 0
         if world > 1:
@@ -137,6 +139,7 @@ def main():
             if rank == 0:
                 s = r.stats()  # waits for this step's kernel (HIP events on the launch stream)
                 kernel_ms.append(s["kernel_ms"]); rays, paths = s["rays"], s["paths"]
+        pipe.drain()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()

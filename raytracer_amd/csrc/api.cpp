@@ -480,7 +480,8 @@ int32_t rthip_set_accum_buffer(rthip_ctx* c, void* device_ptr, uint64_t n_words)
 	if (!c) return RTHIP_ERR_INVALID;
 	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	// No wait here: launches already queued carry the pointer they were given, and later calls
+	// are ordered behind them on the stream.
 	if (!device_ptr) { c->accum = nullptr; c->accum_words = 0; return ensure_accum(c); }
 	uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
 	if (n_words != words) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must hold tiles_x*tiles_y*192 words");

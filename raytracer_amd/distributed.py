@@ -45,6 +45,46 @@ def merge_accum(accum, dst=0, group=None):
     return accum
 
 
+class MergePipeline:
+    """Double-buffered merge for a stream of frames: while frame k's accumulation buffer is being
+    reduced (RCCL runs on its own stream), frame k + 1 renders into the other buffer, so the
+    collective hides behind tracing instead of adding to every frame.
+
+        buf = pipe.acquire()      # the buffer of this frame; waits for the reduce that last used it
+        ... zero it, render into it ...
+        pipe.release()            # starts the (asynchronous) reduce of this frame
+        pipe.drain()              # after the last frame
+
+    On rank `dst`, the buffer handed out two frames ago holds that frame's merged sums (read it
+    after acquire() returns it again, or after drain())."""
+
+    def __init__(self, make_buffer, dst=0, group=None):
+        self.bufs = [make_buffer(), make_buffer()]
+        self.pending = [None, None]
+        self.dst, self.group, self.k = dst, group, 0
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def acquire(self):
+        i = self.k % 2
+        if self.pending[i] is not None:
+            self.pending[i].wait()   # NCCL: makes the current stream wait, the host does not block
+            self.pending[i] = None
+        return self.bufs[i]
+
+    def release(self):
+        i = self.k % 2
+        if self.active:
+            self.pending[i] = dist.reduce(self.bufs[i], dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.k += 1
+        return self.bufs[i]
+
+    def drain(self):
+        for i in (0, 1):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+
+
 def accum_to_image(accum, width, height):
     """Decode a (merged) accumulation buffer to sum_s sqrt(sample), float64 [H, W, 3], on the host."""
     words = accum.detach().cpu().numpy().view(np.uint64)

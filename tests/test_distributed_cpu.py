@@ -72,3 +72,44 @@ def test_partitions_cover_everything_once():
         owners = sum(((tiles % world) == D.tile_part(r, world)[0]).astype(int) for r in range(world))
         assert (owners == 1).all()
     assert D.accum_words(1920, 1080) == 240 * 135 * 192
+
+
+def _pipeline_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracer_amd import distributed as D
+    n = D.accum_words(W, H)
+    pipe = D.MergePipeline(lambda: torch.zeros(n, dtype=torch.int64), dst=0)
+    seen = []
+    frames = 5
+    for k in range(frames):
+        buf = pipe.acquire()
+        if k >= 2 and rank == 0:
+            seen.append(buf.clone())          # frame k - 2, merged
+        buf.zero_()
+        buf += (rank + 1) * (k + 1) + torch.arange(n, dtype=torch.int64) % 7   # this rank's "render" of frame k
+        pipe.release()
+    pipe.drain()
+    if rank == 0:
+        seen.append(pipe.bufs[(frames - 2) % 2].clone())
+        seen.append(pipe.bufs[(frames - 1) % 2].clone())
+        torch.save(torch.stack(seen), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_double_buffered_merge_pipeline(tmp_path):
+    """Frames stream through two buffers; every frame's reduce completes before its buffer is
+    reused, and rank 0 ends up with each frame's sum over ranks."""
+    sys.path.insert(0, ROOT)
+    from raytracer_amd import distributed as D
+    out = str(tmp_path / "frames.pt")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_pipeline_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    n = D.accum_words(W, H)
+    base = torch.arange(n, dtype=torch.int64) % 7
+    assert got.shape[0] == 5
+    for k in range(5):
+        assert torch.equal(got[k], (1 + 2) * (k + 1) + 2 * base), k
