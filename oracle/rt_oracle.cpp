@@ -5,10 +5,11 @@
 // operation order, so that results agree with the Rust code to the last bit wherever the
 // Rust code itself is deterministic.  Compile with -ffp-contract=off (see Makefile).
 //
-// Parity status: the reference ships no tests, golden vectors or fixtures for this path and
-// cannot be compiled in this environment (no Rust toolchain), so this restatement is pinned
-// by source reading plus closed-form known-answer tests only.  The random stream is
-// "parity unpinned" by design: the reference draws from an OS-seeded ThreadRng
+// Parity status: PARITY UNPINNED.  The reference ships no tests, golden vectors or fixtures for
+// this path and cannot be compiled in this environment (no Rust toolchain), so nothing produced
+// by the reference itself anchors this restatement: it rests on source reading plus closed-form
+// known-answer tests.  The random stream is unpinned by design: the reference draws from an
+// OS-seeded ThreadRng
 // (raytracer_headless/src/main.rs:40), so only the distributions and the per-event draw
 // counts are contractual; the stream used here is the counter-based generator that the HIP
 // kernels also implement.
