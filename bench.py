@@ -28,13 +28,24 @@ RENDER_SEED = 0x5EED0001
 HEADLESS_CAMERA = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)  # raytracer_headless/src/main.rs:20-28
 PEAK_FP32_VALU_TFLOPS = 157.3
 
+def _wallpaper_camera():
+    return ((0.0, 0.0, 0.0), rt.get_camera_rotation(-90.0, 0.0), 90.0, 10.0, 0.6)   # raytracer_gpu/src/main.rs:70
+
+
 WORKLOADS = {
     # BASELINE.json configs[1]: the headless default scene at 1080p, 100 spp, depth 10
-    "cfg2": dict(scene="default", width=1920, height=1080, spp=100, depth=10,
+    "cfg2": dict(scene="default", width=1920, height=1080, spp=100, depth=10, sky=0, camera=lambda: HEADLESS_CAMERA, bound="valu_fp32",
                  desc="configs[1]: Scene::create_sample_scene (seed 0x5EED0001), headless camera, 1920x1080, 100 spp, depth 10"),
     # BASELINE.json configs[2]: many spheres and cubes, 1080p, 500 spp, depth 50
-    "cfg3": dict(scene="sample", width=1920, height=1080, spp=500, depth=50,
+    "cfg3": dict(scene="sample", width=1920, height=1080, spp=500, depth=50, sky=0, camera=lambda: HEADLESS_CAMERA, bound="valu_fp32",
                  desc="configs[2]: scenes::create_sample_scene (many spheres and cubes, seed 0x5EED0001), headless camera, 1920x1080, 500 spp, depth 50"),
+    # BASELINE.json configs[3]: wallpaper scene at 4K (2000 spp in the config: here 100 spp per step, throughput is spp-independent)
+    "cfg4": dict(scene="wallpaper", width=3840, height=2160, spp=100, depth=10, sky=1, camera=_wallpaper_camera, bound="valu_fp32",
+                 desc="configs[3]: scenes::create_wallpaper_scene, camera origin 0 / yaw -90 / fov 90, wallpaper sky, 3840x2160, 100 spp per step (of 2000), depth 10"),
+    # BASELINE.json configs[4]: one million random spheres and cubes at 8K (tree and primitives in HBM / L2)
+    "cfg5": dict(scene="synthetic:1000000", width=7680, height=4320, spp=16, depth=50, sky=0, bound="hbm",
+                 camera=lambda: ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0),
+                 desc="configs[4]: synthetic 1,000,000 spheres + cubes (seed 0x5EED0001), camera (0,60,-550) looking at the origin, fov 40, 7680x4320, 16 spp, depth 50"),
 }
 
 
@@ -51,30 +62,48 @@ def cpu_side(scene, wl, run_baseline):
     reduced frame of the same view, and the reference algorithm (FAITHFUL) timed on a bounded
     sample of the workload."""
     from oracle import binding as ob  # measurement only: never on the product path
+    print("[bench] oracle: building the reference tree and counting algorithmic work", file=sys.stderr, flush=True)
     osc = ob.OracleScene(scene.objects)
-    cam_small = ob.camera_desc(*HEADLESS_CAMERA, wl["width"] // 8, wl["height"] // 8)
-    _, _, cnt, _ = osc.render(cam_small, 4, wl["depth"], RENDER_SEED, ob.TIGHT, threads=host_threads())
+    camera = wl["camera"]()
+    shrink = 8 if len(scene) < 100000 else 32   # the million-object scene: count work on a 240x135 frame
+    cam_small = ob.camera_desc(*camera, wl["width"] // shrink, wl["height"] // shrink)
+    _, _, cnt, _ = osc.render(cam_small, 4 if shrink == 8 else 1, wl["depth"], RENDER_SEED, ob.TIGHT, sky_mode=wl["sky"], threads=host_threads())
     work = dict(flop_per_path=ob.algorithmic_flops(cnt) / cnt["paths"], bytes_per_path=ob.algorithmic_bytes(cnt) / cnt["paths"],
                 rays_per_path=cnt["rays"] / cnt["paths"], box_tests_per_ray=cnt["box_tests"] / cnt["rays"],
                 prim_tests_per_ray=(cnt["sphere_tests"] + cnt["cube_tests"]) / cnt["rays"])
     baseline = None
     if run_baseline:
         threads = host_threads()
-        cam_full = ob.camera_desc(*HEADLESS_CAMERA, wl["width"], wl["height"])
-        # size the sample to ~15 s of CPU work from a quick probe: whole frames when they are
-        # cheap enough (spp >= 1), else a centred band of rows at 1 spp
-        _, _, c0, s0 = osc.render(cam_small, 2, wl["depth"], RENDER_SEED, ob.FAITHFUL, threads=threads)
-        budget_paths = 15.0 * c0["paths"] / s0
-        frame = wl["width"] * wl["height"]
-        if budget_paths >= frame:
-            spp, rows, y0 = int(min(wl["spp"], budget_paths // frame)), wl["height"], 0
+        W, Hh = wl["width"], wl["height"]
+        cam_full = ob.camera_desc(*camera, W, Hh)
+        print(f"[bench] cpu baseline: probing the reference algorithm on {threads} threads", file=sys.stderr, flush=True)
+        if shrink == 8:
+            # size the sample to ~15 s of CPU work from a quick probe: whole frames when they are
+            # cheap enough (spp >= 1), else a centred band of rows at 1 spp
+            _, _, c0, s0 = osc.render(cam_small, 2, wl["depth"], RENDER_SEED, ob.FAITHFUL, sky_mode=wl["sky"], threads=threads)
+            budget_paths = 15.0 * c0["paths"] / s0
+            frame = W * Hh
+            if budget_paths >= frame:
+                spp, win = int(min(wl["spp"], budget_paths // frame)), (0, 0, W, Hh)
+            else:
+                rows = int(max(8, budget_paths // W))
+                spp, win = 1, (0, (Hh - rows) // 2, W, (Hh - rows) // 2 + rows)
         else:
-            spp, rows = 1, int(max(8, budget_paths // wl["width"]))
-            y0 = (wl["height"] - rows) // 2
-        _, _, c1, s1 = osc.render(cam_full, spp, wl["depth"], RENDER_SEED, ob.FAITHFUL, threads=threads,
-                                  window=(0, y0, wl["width"], y0 + rows))
+            # The reference's walk tests nearly every primitive of a million-object scene per ray
+            # (~20 ms per ray): time a centred crop of the full-resolution frame, one row per thread
+            # at least, sized from a probe to ~20 s.
+            x0, y0 = W // 2 - 8, Hh // 2 - threads // 2
+            _, _, c0, s0 = osc.render(cam_full, 1, wl["depth"], RENDER_SEED, ob.FAITHFUL, sky_mode=wl["sky"], threads=threads,
+                                      window=(x0, y0, x0 + 16, y0 + threads))
+            per_path = s0 * threads / c0["paths"]                     # thread-seconds per path
+            cols = int(max(16, min(128, 20.0 * threads / per_path / 72)))
+            rows = int(max(threads, min(72, 20.0 * threads / per_path / cols)))
+            x0, y0 = (W - cols) // 2, (Hh - rows) // 2
+            spp, win = 1, (x0, y0, x0 + cols, y0 + rows)
+        print(f"[bench] cpu baseline: timing window {win}, {spp} spp", file=sys.stderr, flush=True)
+        _, _, c1, s1 = osc.render(cam_full, spp, wl["depth"], RENDER_SEED, ob.FAITHFUL, sky_mode=wl["sky"], threads=threads, window=win)
         baseline = dict(value=c1["paths"] / s1 / 1e6, unit="Mpaths/s", cores=threads, kind="port",
-                        sample=f"rows {y0}..{y0 + rows} of the {wl['width']}x{wl['height']} frame, {spp} spp, depth {wl['depth']}: "
+                        sample=f"pixels x {win[0]}..{win[2]}, y {win[1]}..{win[3]} of the {W}x{Hh} frame, {spp} spp, depth {wl['depth']}: "
                                f"{c1['paths']} paths in {s1:.1f} s; f64 restatement of the reference algorithm "
                                f"(recursive both-children BVH walk, per-axis AABB test), row-parallel on {threads} threads",
                         mrays_per_s=c1["rays"] / s1 / 1e6)
@@ -111,8 +140,8 @@ def main():
         if spp_override:
             wl["spp"] = spp_override
         scene = rt.Scene.generate(wl["scene"], SCENE_SEED)
-        cam = rt.Camera(*HEADLESS_CAMERA, wl["width"], wl["height"])
-        r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED)
+        cam = rt.Camera(*wl["camera"](), wl["width"], wl["height"])
+        r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"])
         stream = torch.cuda.current_stream(device)
         r.set_stream(stream.cuda_stream)
         pipe = D.MergePipeline(lambda: D.new_accum_tensor(wl["width"], wl["height"], device), dst=0)
@@ -192,17 +221,29 @@ def main():
             if os.path.exists(tpath):  # measured with rocprofv3 counters (bytes per path), scaled to this launch
                 t = json.load(open(tpath)).get(args.workload)
                 traffic = t["hbm_bytes_per_path"] * res["paths"] if t else None
-            line["roofline"] = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                                "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "kernel": "render_kernel<float>",
-                                "kernel_ms": res["kernel_ms"], "algorithmic_flop_per_path": work["flop_per_path"],
-                                "algorithmic_bytes_per_path": work["bytes_per_path"], "box_tests_per_ray": work["box_tests_per_ray"],
-                                "prim_tests_per_ray": work["prim_tests_per_ray"]}
+            valu = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "kernel": "render_kernel<float>",
+                    "kernel_ms": res["kernel_ms"], "algorithmic_flop_per_path": work["flop_per_path"],
+                    "algorithmic_bytes_per_path": work["bytes_per_path"], "box_tests_per_ray": work["box_tests_per_ray"],
+                    "prim_tests_per_ray": work["prim_tests_per_ray"]}
+            line["roofline"] = valu
+            if wl["bound"] == "hbm":
+                # Scene in global memory: every node and primitive record a ray reads comes through L1/L2.
+                # The algorithmic bytes (oracle TIGHT counts on the reference-shaped tree) over time
+                # exceed the HBM roof whenever caches serve most of them; `traffic` is what actually
+                # missed L2 (rocprofv3 FETCH_SIZE + WRITE_SIZE), the figure to hold against 8 TB/s.
+                gbs = work["bytes_per_path"] * res["paths"] / (res["kernel_ms"] * 1e-3) / 1e9
+                line["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
+                                        "measured_l2_miss_gbs": (traffic / (res["kernel_ms"] * 1e-3) / 1e9) if traffic else None,
+                                        "kernel": "render_kernel<float> (scene in global memory)",
+                                        "note": "latency bound: 70 % of wave cycles wait on memory (profiles/r01/cfg5_pmc_summary.json)"}
             # the same launch against the memory roof: what the algorithm must move through HBM is one
             # read-modify-write of the accumulation words of every pixel (scene and ray state stay on chip)
             hbm_alg = wl["width"] * wl["height"] * 3 * 8 * 2
             gbs = hbm_alg / (res["kernel_ms"] * 1e-3) / 1e9
-            line["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
-                                    "note": "not the binding roof: the kernel is VALU-issue bound"}
+            if wl["bound"] != "hbm":
+                line["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
+                                        "note": "not the binding roof: the kernel is VALU-issue bound"}
         if baseline:
             line["cpu_baseline"] = baseline
             line["speedup_vs_cpu"] = value / baseline["value"]

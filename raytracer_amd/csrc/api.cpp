@@ -45,7 +45,7 @@ struct rthip_ctx {
 	unsigned long long* accum = nullptr;  // active buffer (own or caller's)
 	uint64_t accum_words = 0;
 
-	char* d_control = nullptr;  // 512 bytes: queue counter at +0, statistics words from +8
+	char* d_control = nullptr;  // 1024 bytes: statistics words from +8, work-queue counters from +512 (one per 64-byte line)
 	// wavefront variant: ping-pong path state, hit records and the per-bounce counter block
 	char* wf_mem = nullptr;
 	size_t wf_bytes = 0;
@@ -191,9 +191,9 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.inner_exit = env_int("RTHIP_INNER_EXIT", plan.cfg.scene_in_lds ? 5 : 8);
 	a.regen_min = std::max(1, std::min(64, env_int("RTHIP_REGEN_MIN", 16)));
 	a.accum = accum; a.samples_out = samples_out;
-	a.queue = reinterpret_cast<uint32_t*>(c->d_control);
+	a.queue = reinterpret_cast<uint32_t*>(c->d_control + 512);
 	a.stats = reinterpret_cast<unsigned long long*>(c->d_control + 8);
-	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 512, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 1024, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
 	if (plan.n_items > 0 && p->spp_count > 0) HIP_TRY(c, launch_render(a, plan.cfg, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -250,7 +250,7 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 	const int depth = std::max(0, p->max_depth);
 	uint32_t* n = c->wf_counters;
 	uint32_t* fetch = c->wf_counters + kWfMaxDepth + 1;
-	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 512, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 1024, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
 	for (uint64_t begin = 0; begin < total && p->spp_count > 0; begin += batch) {
 		HIP_TRY(c, hipMemsetAsync(c->wf_counters, 0, (2 * kWfMaxDepth + 2) * sizeof(uint32_t), c->stream));
@@ -342,7 +342,7 @@ int32_t rthip_create(int32_t device, rthip_ctx** out) {
 	c->stream = c->own_stream;
 	if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
 	if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-	if ((e = hipMalloc(&c->d_control, 512)) != hipSuccess) return bail("hipMalloc", e);
+	if ((e = hipMalloc(&c->d_control, 1024)) != hipSuccess) return bail("hipMalloc", e);
 	*out = c;
 	return RTHIP_OK;
 }

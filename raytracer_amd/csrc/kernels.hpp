@@ -41,6 +41,7 @@ namespace rthip {
 #ifndef RT_MINWAVES
 #define RT_MINWAVES 6
 #endif
+constexpr uint32_t kQueues = 8;   // work-item ranges, one per XCD of the part
 constexpr int kProbeBlock = 256;  // threads per workgroup of the parity probe
 constexpr int kDone = INT32_MIN;  // traversal finished (not a valid leaf code)
 
@@ -63,7 +64,7 @@ struct RenderArgs {
 	int32_t inner_exit;     // sixteenths: leave the inner-node loop when fewer lanes than this share of the round remain in it
 	unsigned long long* accum;    // [tiles][3 channels][64 px] fixed point
 	Real* samples_out;            // optional [spp_count][H][W][3]
-	uint32_t* queue;              // work-item counter, zeroed before the launch
+	uint32_t* queue;              // kQueues work-item counters, one per 64-byte line, zeroed before the launch
 	unsigned long long* stats;    // [0] paths [1] rays [2] box tests [3] sphere tests [4] cube tests, then region counters
 };
 
@@ -692,7 +693,12 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	ray.inv_xy = ray.noi_xy = ray.inv_zz = ray.noi_zz = f2{0.0f, 0.0f};
 
 	// wave state (uniform)
-	uint32_t item = 0, pool_pos = 0, pool_end = 0;
+	// Work items are cut into kQueues contiguous ranges (bands of the image), each with its own
+	// counter.  Workgroups whose index agrees modulo 8 share an XCD and its L2, so they start on the
+	// same range and the rays an L2 serves stay in one part of the scene; a wave whose range is
+	// exhausted moves on to the next one (all ranges get finished whatever the placement).
+	uint32_t item = 0, pool_pos = 0, pool_end = 0, queue_hop = 0;
+	const uint32_t home_queue = blockIdx.x % kQueues;
 	bool queue_dry = false;
 	const uint32_t pool_size = 64u * A.chunk;
 
@@ -722,11 +728,19 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			if ((int32_t)__popcll(need) < A.regen_min && need != ~0ull) break;  // wait for more idle lanes: camera rays for few lanes waste the wave
 			if (pool_pos == pool_end) {
 				if (queue_dry) break;
-				uint32_t it = 0;
-				if (lane == 0) it = atomicAdd(A.queue, 1u);
-				it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
-				if (it >= A.n_items) { queue_dry = true; break; }
-				item = it; pool_pos = 0; pool_end = pool_size;
+				bool got = false;
+				while (queue_hop < kQueues) {
+					const uint32_t q = (home_queue + queue_hop) % kQueues;
+					const uint32_t begin = (uint32_t)((unsigned long long)A.n_items * q / kQueues);
+					const uint32_t end = (uint32_t)((unsigned long long)A.n_items * (q + 1u) / kQueues);
+					uint32_t it = 0;
+					if (lane == 0) it = atomicAdd(A.queue + q * 16u, 1u);
+					it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+					if (it < end - begin) { item = begin + it; got = true; break; }
+					queue_hop++;
+				}
+				if (!got) { queue_dry = true; break; }
+				pool_pos = 0; pool_end = pool_size;
 			}
 			uint32_t want = (uint32_t)__popcll(need);
 			uint32_t avail = pool_end - pool_pos;
