@@ -15,12 +15,14 @@
 //
 // Execution model.  One launch renders `spp_count` samples of every pixel the call owns.  The
 // grid is persistent: every wave pulls work items (an 8x8 tile x `chunk` samples = 64*chunk
-// paths) from a global counter and keeps its 64 lanes busy by handing a finished lane the next
-// path of the wave's pool (ballot + mbcnt ranking), so lanes are not tied to pixels.  A lane is
-// a small state machine: IDLE -> TRAVERSE -> SHADE -> (TRAVERSE | IDLE).  The wave alternates
-// between a traversal loop, which it leaves once the number of lanes still traversing drops
-// under a threshold while other lanes wait, and a shading/regeneration step; lanes interrupted
-// mid-traversal keep their stack and simply continue on the next round.  The per-lane
+// paths) from one of eight counters (one per range of the image, so that the workgroups that
+// share an XCD's L2 work on one band) and keeps its 64 lanes busy by handing finished lanes the
+// next paths of the wave's pool (ballot + mbcnt ranking), so lanes are not tied to pixels.  A
+// lane is a small state machine: IDLE -> FRESH -> TRAVERSE -> SHADE -> (FRESH | IDLE).  The wave
+// alternates between shading, regeneration (once enough lanes are idle), ray set-up, and a
+// traversal loop, which it leaves once the number of lanes still traversing drops under a
+// threshold while the other steps have lanes to serve; lanes interrupted mid-traversal keep
+// their stack and simply continue on the next round.  The per-lane
 // traversal stack lives in LDS ([entry][thread], conflict-free); scenes that fit are copied to
 // LDS as well, so the inner loop touches no global memory.  Finished paths add sqrt(radiance)
 // to the accumulation buffer as 64-bit fixed-point integers (atomic adds commute exactly, so
