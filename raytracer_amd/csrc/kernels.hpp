@@ -231,15 +231,11 @@ RT_FN V3<Real> sky(V3<Real> dir, int sky_mode) {
 // ---------------------------------------------------------------------------------------
 // A ray prepared for traversal.
 // ---------------------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
 template <typename Real> struct TravRay {
 	V3<Real> o, d, inv;  // inv = 1 / d
 	V3<Real> noi;        // -(o * inv): the f32 box test is one fma per plane, plane * inv + noi
 	Real eps;            // absolute slack that covers the rounding of that fma form
 	Real rcp_a;          // 1 / d.d (f32 sphere test)
-	// f32 box test operands as register pairs for the packed FMA: (inv.x, inv.y), (noi.x, noi.y),
-	// (inv.z, inv.z), (noi.z, noi.z).  Unused (and dropped by the compiler) in f64.
-	f2 inv_xy, noi_xy, inv_zz, noi_zz;
 };
 RT_FN TravRay<Real> prepare(RayT<Real> r) {
 	TravRay<Real> t;
@@ -266,8 +262,6 @@ RT_FN TravRay<Real> prepare(RayT<Real> r) {
 	Real ez = az >= floor_d ? Fp<Real>::fabs(t.noi.z) : Real(0);
 	t.eps = Fp<Real>::fmax(Fp<Real>::fmax(ex, ey), ez) * Real(0x1p-21);
 	t.rcp_a = Fp<Real>::rcp(dot(r.d, r.d));
-	t.inv_xy = f2{(float)t.inv.x, (float)t.inv.y}; t.noi_xy = f2{(float)t.noi.x, (float)t.noi.y};
-	t.inv_zz = f2{(float)t.inv.z, (float)t.inv.z}; t.noi_zz = f2{(float)t.noi.z, (float)t.noi.z};
 	return t;
 }
 
@@ -340,13 +334,14 @@ RT_FN bool hit_cube(const Prim<Real>& c, const TravRay<Real>& r, Real* t) {
 // drops out of min/max, which only makes the test more permissive.
 RT_FN bool hit_box(const Real* b, const TravRay<Real>& r, Real best_t, Real* entry) {
 	if constexpr (std::is_same<Real, float>::value && RT_FUSED_BOX) {
-		const f2* p = reinterpret_cast<const f2*>(b);
-		f2 lo = __builtin_elementwise_fma(p[0], r.inv_xy, r.noi_xy);  // v_pk_fma_f32: two planes per instruction
-		f2 hi = __builtin_elementwise_fma(p[1], r.inv_xy, r.noi_xy);
-		f2 zz = __builtin_elementwise_fma(p[2], r.inv_zz, r.noi_zz);
-		float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(lo.x, hi.x), Fp<float>::fmin(lo.y, hi.y)), Fp<float>::fmin(zz.x, zz.y));
-		float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(lo.x, hi.x), Fp<float>::fmax(lo.y, hi.y)),
-		                             Fp<float>::fmin(Fp<float>::fmax(zz.x, zz.y), best_t));
+		// One v_fma_f32 per plane.  (The two-wide v_pk_fma_f32 halves the instruction count here but
+		// measured 2-4 % slower in this divergent loop.)
+		float x0 = __builtin_fmaf(b[kBoxLoX], r.inv.x, r.noi.x), x1 = __builtin_fmaf(b[kBoxHiX], r.inv.x, r.noi.x);
+		float y0 = __builtin_fmaf(b[kBoxLoY], r.inv.y, r.noi.y), y1 = __builtin_fmaf(b[kBoxHiY], r.inv.y, r.noi.y);
+		float z0 = __builtin_fmaf(b[kBoxLoZ], r.inv.z, r.noi.z), z1 = __builtin_fmaf(b[kBoxHiZ], r.inv.z, r.noi.z);
+		float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(x0, x1), Fp<float>::fmin(y0, y1)), Fp<float>::fmin(z0, z1));
+		float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(x0, x1), Fp<float>::fmax(y0, y1)),
+		                             Fp<float>::fmin(Fp<float>::fmax(z0, z1), best_t));
 		*entry = tnear;
 		return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, r.eps);
 	} else {
@@ -692,7 +687,6 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	rng.state = 0; rng.inc = 1;
 	T = L = mk<Real>(0, 0, 0);
 	ray.o = ray.d = ray.inv = ray.noi = T; ray.eps = ray.rcp_a = 0;
-	ray.inv_xy = ray.noi_xy = ray.inv_zz = ray.noi_zz = f2{0.0f, 0.0f};
 
 	// wave state (uniform)
 	// Work items are cut into kQueues contiguous ranges (bands of the image), each with its own

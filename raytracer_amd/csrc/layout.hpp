@@ -25,10 +25,10 @@ constexpr int kMaxObjects = 1 << 25;  // leaf code holds the first primitive in 
 // child >= 0: index of an inner node.  child < 0: leaf, ~child = first_prim << 6 | n_spheres << 3 | n_cubes.
 constexpr int32_t leaf_code(int32_t first, int32_t ns, int32_t nc) { return ~((first << 6) | (ns << 3) | nc); }
 
-// Plane order inside one child box of a Node: (lo.x, lo.y), (hi.x, hi.y), (lo.z, hi.z).  The f32
-// box test multiplies the first two pairs by (1/d.x, 1/d.y) and the third by (1/d.z, 1/d.z) with
-// packed two-wide FMAs, so each pair sits in one aligned 8-byte slot.
-constexpr int kBoxLoX = 0, kBoxLoY = 1, kBoxHiX = 2, kBoxHiY = 3, kBoxLoZ = 4, kBoxHiZ = 5;
+// Plane order inside one child box of a Node (and of an f32 cube): lo.xyz, hi.xyz.  Kept behind
+// names because it was not always so: a paired order (lo.x, lo.y) (hi.x, hi.y) (lo.z, hi.z) fed
+// two-wide packed FMAs, which measured slower than one scalar FMA per plane.
+constexpr int kBoxLoX = 0, kBoxLoY = 1, kBoxLoZ = 2, kBoxHiX = 3, kBoxHiY = 4, kBoxHiZ = 5;
 
 template <typename Real>
 struct alignas(sizeof(Real) * 16) Node {
@@ -40,7 +40,7 @@ static_assert(sizeof(Node<double>) == 128, "f64 node is 128 bytes");
 
 // Sphere: v = centre.xyz, radius, gate word (see Gate), 0.
 // Cube, f64: v = centre.xyz, half_extent.xyz (the reference's own representation).
-// Cube, f32: v = the six face planes in the order of kBox* (like a node's child box), computed
+// Cube, f32: v = the six face planes lo.xyz, hi.xyz (the order of kBox*), computed
 //            in f64 as centre -/+ half_extent and rounded once, so that huge cubes (ground slabs
 //            of half extent 1e5) keep exact faces.
 template <typename Real>

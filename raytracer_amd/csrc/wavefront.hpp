@@ -161,7 +161,6 @@ __global__ __launch_bounds__(kThreads) void wf_extend(WfArgs<Real> A) {
 	Regions rg{};
 	tv.cur = kDone; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
 	ray.o = ray.d = ray.inv = ray.noi = mk<Real>(0, 0, 0); ray.eps = ray.rcp_a = 0;
-	ray.inv_xy = ray.noi_xy = ray.inv_zz = ray.noi_zz = f2{0.0f, 0.0f};
 	uint32_t pool_pos = 0, pool_end = 0;
 	bool dry = false;
 
