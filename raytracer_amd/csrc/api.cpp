@@ -157,7 +157,12 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	if (cap > 0) bpc = std::min(bpc, cap);
 	uint64_t n_tiles = (uint64_t)c->tiles_x * c->tiles_y;
 	uint64_t my_tiles = n_tiles > (uint64_t)p->part_index ? (n_tiles - p->part_index + p->part_count - 1) / p->part_count : 0;
-	uint32_t chunk = (uint32_t)std::max(1, env_int("RTHIP_CHUNK", 8));
+	// Samples of a tile per work item.  Small items balance short launches (the tail is one item per
+	// wave); long launches want fewer, larger items (millions of items contend on the queue counters
+	// and scatter a tile's accumulation lines).  Measured optimum: 4 up to ~128 spp, 8-16 beyond.
+	uint32_t auto_chunk = 4;
+	while (auto_chunk < 16 && auto_chunk * 64 <= p->spp_count) auto_chunk *= 2;
+	uint32_t chunk = (uint32_t)std::max(1, env_int("RTHIP_CHUNK", (int)auto_chunk));
 	chunk = std::min<uint32_t>(chunk, std::max<uint32_t>(1u, p->spp_count));
 	uint32_t n_chunks = (p->spp_count + chunk - 1) / chunk;
 	uint64_t n_items = my_tiles * n_chunks;
