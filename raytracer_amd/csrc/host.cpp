@@ -689,7 +689,35 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 			b.items.push_back(it);
 		}
 		size_t m = b.items.size();
-		if (m <= (size_t)b.max_leaf) {
+		// Large scenes: a few primitives that dwarf the rest (a ground slab, a sun) would stretch the
+		// box of every node above them.  They go into one leaf of their own, the left child of the
+		// root, and the surface-area build runs over the rest (its root is the right child).
+		std::vector<int32_t> big;
+		if (m > 4096 && !std::getenv("RTHIP_NO_BIG_LEAF")) {
+			auto diag = [](const Builder::Item& it) {
+				double dx = it.b.hi[0] - it.b.lo[0], dy = it.b.hi[1] - it.b.lo[1], dz = it.b.hi[2] - it.b.lo[2];
+				return std::sqrt(dx * dx + dy * dy + dz * dz);
+			};
+			std::vector<double> d(m);
+			for (size_t i = 0; i < m; i++) d[i] = diag(b.items[i]);
+			std::nth_element(d.begin(), d.begin() + (long)(m / 2), d.end());
+			const double limit = 64.0 * d[m / 2];
+			int ns = 0, nc = 0;
+			for (size_t i = 0; i < m; i++)
+				if (diag(b.items[i]) > limit) { big.push_back(b.items[i].id); (objs[b.items[i].id].kind == RTHIP_SPHERE ? ns : nc)++; }
+			if (big.empty() || ns > 7 || nc > 7) {
+				big.clear();  // none, or more than one leaf code can hold: leave the tree as it is
+			} else {
+				b.items.erase(std::remove_if(b.items.begin(), b.items.end(), [&](const Builder::Item& it) { return diag(it) > limit; }), b.items.end());
+				m = b.items.size();
+			}
+		}
+		if (!big.empty()) {
+			Builder::Sub bl = b.emit_leaf(big.data(), (int)big.size());  // node 0 is already reserved for the root
+			Builder::Sub rest = b.sah_build(0, m, 1);
+			b.write_node(root, bl, rest);
+			if (b.max_depth < 1) b.max_depth = 1;
+		} else if (m <= (size_t)b.max_leaf) {
 			l = m ? b.sah_leaf(0, m) : r;
 		} else {
 			// the root's two children are the two halves of the first split
@@ -699,7 +727,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 			(void)whole;
 			root = 0;
 		}
-		if (m <= (size_t)b.max_leaf) { b.write_node(root, l, r); b.max_depth = 1; }
+		if (big.empty() && m <= (size_t)b.max_leaf) { b.write_node(root, l, r); b.max_depth = 1; }
 	} else {
 		if (b.ref_nodes[(size_t)ref_root].left < 0) {
 			l = b.shape_ref(ref_root, 0);
