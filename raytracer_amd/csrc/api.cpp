@@ -22,6 +22,8 @@ struct SceneBlob {  // one precision of the scene in HBM: [nodes | prims | mats]
 	char* dev = nullptr;
 	uint32_t prims_off = 0, mats_off = 0, gates_off = 0, bytes = 0;
 	uint32_t lds_bytes = 0;  // nodes + prims + gates: what an LDS-resident launch copies
+	uint32_t qnodes_off = 0; // quantised nodes behind the materials (f32 blob of a large scene), 0 = none
+	QFrame qframe{};
 };
 inline uint32_t align_up(uint64_t v, uint32_t a) { return (uint32_t)((v + a - 1) / a * a); }
 }  // namespace
@@ -80,11 +82,14 @@ template <typename Real> void fill_camera(const CameraFields& f, CameraT<Real>* 
 
 template <typename Real>
 int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const std::vector<Prim<Real>>& prims,
-                    const std::vector<Mat<Real>>& mats, const std::vector<Gate<Real>>& gates, SceneBlob* b) {
+                    const std::vector<Mat<Real>>& mats, const std::vector<Gate<Real>>& gates, SceneBlob* b,
+                    const std::vector<QNode>* qnodes = nullptr, const QFrame* qframe = nullptr) {
 	uint64_t nb = nodes.size() * sizeof(Node<Real>), pb = prims.size() * sizeof(Prim<Real>), mb = mats.size() * sizeof(Mat<Real>);
 	uint64_t gb = gates.size() * sizeof(Gate<Real>);
 	uint64_t prims_off = align_up(nb, 64), gates_off = align_up(prims_off + pb, 64), mats_off = align_up(gates_off + gb, 64);
-	uint64_t total = align_up(mats_off + mb, 64);
+	uint64_t qb = (qnodes && !qnodes->empty()) ? qnodes->size() * sizeof(QNode) : 0;
+	uint64_t q_off = align_up(mats_off + mb, 64);
+	uint64_t total = align_up(q_off + qb, 64);
 	if (total > 0xFFFFFFF0ull) return fail(c, RTHIP_ERR_LIMIT, "scene larger than 4 GiB");
 	if (b->dev) { HIP_TRY(c, hipFree(b->dev)); b->dev = nullptr; }
 	std::vector<char> host((size_t)total, 0);
@@ -92,6 +97,9 @@ int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const st
 	std::memcpy(host.data() + prims_off, prims.data(), (size_t)pb);
 	std::memcpy(host.data() + mats_off, mats.data(), (size_t)mb);
 	if (gb) std::memcpy(host.data() + gates_off, gates.data(), (size_t)gb);
+	if (qb) std::memcpy(host.data() + q_off, qnodes->data(), (size_t)qb);
+	b->qnodes_off = qb ? (uint32_t)q_off : 0u;
+	if (qb) b->qframe = *qframe;
 	HIP_TRY(c, hipMalloc(&b->dev, (size_t)total));
 	HIP_TRY(c, hipMemcpy(b->dev, host.data(), (size_t)total, hipMemcpyHostToDevice));
 	b->prims_off = (uint32_t)prims_off; b->mats_off = (uint32_t)mats_off; b->gates_off = (uint32_t)gates_off; b->bytes = (uint32_t)total;
@@ -135,6 +143,7 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	bool in_lds = lds_mode < 0 ? blob.lds_bytes <= kLdsSceneLimit : (lds_mode != 0 && blob.lds_bytes <= 100 * 1024);
 	plan->cfg.scene_in_lds = in_lds;
 	plan->cfg.count = count;
+	plan->cfg.quantised = !in_lds && !f64 && !wavefront && blob.qnodes_off != 0 && env_int("RTHIP_QNODES", 1) != 0;
 	// Workgroup size: the kernel is latency bound, so pick the size that keeps the most waves
 	// resident.  Every workgroup holds its own LDS copy of the scene, so larger workgroups
 	// amortise it.
@@ -187,6 +196,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	std::memset(&a, 0, sizeof(a));
 	a.scene = blob.dev; a.prims_off = blob.prims_off; a.mats_off = blob.mats_off; a.gates_off = blob.gates_off; a.scene_bytes = blob.bytes;
 	a.lds_bytes = blob.lds_bytes;
+	a.qnodes_off = blob.qnodes_off; a.qframe = blob.qframe;
 	a.stack_entries = c->tree_depth;
 	fill_camera<Real>(c->cam, &a.cam);
 	a.width = c->cam.width; a.height = c->cam.height; a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y;
@@ -390,7 +400,7 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 	std::string err;
 	if (!build_flat_scene(objects, n, &flat, &err)) return fail(c, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
 	c->has_scene = false;
-	int32_t rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32);
+	int32_t rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32, &flat.qnodes, &flat.qframe);
 	if (rc != RTHIP_OK) return rc;
 	rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
 	if (rc != RTHIP_OK) return rc;

@@ -675,6 +675,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	bool use_sah = !(mode && std::string(mode) == "ref");
 	if (const char* v = std::getenv("RTHIP_SAH_LEAF")) b.max_leaf = std::max(1, std::min(7, std::atoi(v)));
 	if (const char* v = std::getenv("RTHIP_SAH_CPRIM")) b.cost_prim = std::atof(v);
+	bool big_ids_empty = true;
 	int32_t root = b.new_node();  // node 0 is the root
 	Builder::Sub l, r;
 	r.code = leaf_code(0, 0, 0);
@@ -712,6 +713,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 				m = b.items.size();
 			}
 		}
+		big_ids_empty = big.empty();
 		if (!big.empty()) {
 			Builder::Sub bl = b.emit_leaf(big.data(), (int)big.size());  // node 0 is already reserved for the root
 			Builder::Sub rest = b.sah_build(0, m, 1);
@@ -741,6 +743,47 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	}
 	out->depth = std::max(1, b.max_depth);
 	if (out->depth > kStackMax) { *err = "tree deeper than the traversal stack"; return false; }
+	// 3. large scenes: the quantised copy of the f32 nodes (see QNode).  The grid spans the boxes
+	// of the surface-area tree; the leaf of oversized primitives stays outside it (node 0, which
+	// holds that leaf and the tree's root, is then not part of the quantised traversal).
+	if (use_sah && out->nodes32.size() > 2048 && !std::getenv("RTHIP_NO_QNODES")) {
+		const Node<float>& n0 = out->nodes32[0];
+		const bool has_big = !big_ids_empty;
+		double lo[3], hi[3];
+		for (int k = 0; k < 3; k++) {
+			static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+			lo[k] = has_big ? n0.box[6 + lo_slot[k]] : std::fmin(n0.box[lo_slot[k]], n0.box[6 + lo_slot[k]]);
+			hi[k] = has_big ? n0.box[6 + hi_slot[k]] : std::fmax(n0.box[hi_slot[k]], n0.box[6 + hi_slot[k]]);
+		}
+		QFrame& f = out->qframe;
+		for (int k = 0; k < 3; k++) {
+			f.centre[k] = (float)(0.5 * (lo[k] + hi[k]));
+			double half = std::fmax(hi[k] - (double)f.centre[k], (double)f.centre[k] - lo[k]);
+			f.step[k] = (float)std::fmax(half / (kQMax - 64), 1e-30);  // headroom for the outward rounding
+		}
+		f.start = has_big ? n0.child[1] : 0;
+		f.big_leaf = has_big ? n0.child[0] : 0;
+		out->qnodes.resize(out->nodes32.size());
+		bool ok = true;
+		for (size_t i = has_big ? 1 : 0; i < out->nodes32.size(); i++) {
+			const Node<float>& n = out->nodes32[i];
+			QNode& q = out->qnodes[i];
+			for (int c = 0; c < 2; c++) {
+				for (int k = 0; k < 3; k++) {
+					static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+					double l = n.box[6 * c + lo_slot[k]], h = n.box[6 * c + hi_slot[k]];
+					if (!(l <= h)) { q.q[6 * c + lo_slot[k]] = kQMax; q.q[6 * c + hi_slot[k]] = -kQMax; continue; }  // empty box: never hit
+					double ql = std::floor((l - (double)f.centre[k]) / (double)f.step[k]) - 1.0;
+					double qh = std::ceil((h - (double)f.centre[k]) / (double)f.step[k]) + 1.0;
+					if (ql < -kQMax || qh > kQMax) ok = false;
+					q.q[6 * c + lo_slot[k]] = (int16_t)std::fmax(ql, -kQMax);
+					q.q[6 * c + hi_slot[k]] = (int16_t)std::fmin(qh, kQMax);
+				}
+				q.child[c] = n.child[c];
+			}
+		}
+		if (!ok) out->qnodes.clear();  // cannot happen with the headroom above; the full nodes are always valid
+	}
 	return true;
 }
 

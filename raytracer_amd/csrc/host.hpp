@@ -34,6 +34,8 @@ struct FlatScene {
 	std::vector<Prim<double>> prims64;
 	std::vector<Mat<double>> mats64;
 	std::vector<Gate<double>> gates64;
+	std::vector<QNode> qnodes;  // f32, large scenes only (empty otherwise): quantised copy of nodes32
+	QFrame qframe{};
 	int depth = 0;      // device tree: levels of inner nodes on the longest root-to-leaf path
 	int ref_depth = 0;  // the same for the reference's tree
 	int n_leaves = 0;

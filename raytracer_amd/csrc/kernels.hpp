@@ -52,6 +52,8 @@ struct RenderArgs {
 	const char* scene;  // [nodes | prims | gates | mats] blob in HBM, each part 64-byte aligned
 	uint32_t prims_off, mats_off, gates_off, scene_bytes;
 	uint32_t lds_bytes;     // leading part of the blob that LDS-resident launches copy (all but the materials)
+	uint32_t qnodes_off;    // quantised nodes (f32 blobs of large scenes), 0 = none
+	QFrame qframe;          // their grid, where traversal starts, and the leaf of oversized primitives
 	int32_t stack_entries;  // tree depth
 	CameraT<Real> cam;
 	int32_t width, height, tiles_x, tiles_y;
@@ -236,8 +238,11 @@ template <typename Real> struct TravRay {
 	V3<Real> noi;        // -(o * inv): the f32 box test is one fma per plane, plane * inv + noi
 	Real eps;            // absolute slack that covers the rounding of that fma form
 	Real rcp_a;          // 1 / d.d (f32 sphere test)
+	V3<Real> qscale;     // quantised nodes only: step / d (noi and eps are then relative to the grid centre)
 };
-RT_FN TravRay<Real> prepare(RayT<Real> r) {
+// `frame` (f32 traversal over quantised nodes) moves the box-test operands into grid units; the
+// primitive tests keep using o, d, inv.
+RT_FN TravRay<Real> prepare(RayT<Real> r, const QFrame* frame = nullptr) {
 	TravRay<Real> t;
 	t.o = r.o; t.d = r.d;
 	t.inv = mk<Real>(Fp<Real>::rcp(r.d.x), Fp<Real>::rcp(r.d.y), Fp<Real>::rcp(r.d.z));
@@ -249,7 +254,17 @@ RT_FN TravRay<Real> prepare(RayT<Real> r) {
 		t.inv.y = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(t.inv.y), 0x1p64f), t.inv.y);
 		t.inv.z = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(t.inv.z), 0x1p64f), t.inv.z);
 	}
-	t.noi = -(r.o * t.inv);
+	V3<Real> box_o = r.o;
+	t.qscale = t.inv;
+	Real reach = Real(0);  // largest |plane| the box test multiplies by inv, beside the origin
+	if constexpr (std::is_same<Real, float>::value) {
+		if (frame) {
+			box_o = r.o - ld3(frame->centre);
+			t.qscale = ld3(frame->step) * t.inv;
+			reach = Real(1);
+		}
+	}
+	t.noi = -(box_o * t.inv);
 	// plane*inv - o*inv is exact to an ulp of |o*inv| (not of the result): widen by 4 ulps of the
 	// largest term.  Only axes the ray actually advances along count (|d_a| >= 2^-12 max|d|): on a
 	// nearly parallel axis that ulp, however many time units it is, is still one ulp of o_a in
@@ -257,9 +272,10 @@ RT_FN TravRay<Real> prepare(RayT<Real> r) {
 	// would make the slack exceed every box of the scene and the ray visit the whole tree.
 	Real ax = Fp<Real>::fabs(r.d.x), ay = Fp<Real>::fabs(r.d.y), az = Fp<Real>::fabs(r.d.z);
 	Real floor_d = Fp<Real>::fmax(Fp<Real>::fmax(ax, ay), az) * Real(0x1p-12);
-	Real ex = ax >= floor_d ? Fp<Real>::fabs(t.noi.x) : Real(0);
-	Real ey = ay >= floor_d ? Fp<Real>::fabs(t.noi.y) : Real(0);
-	Real ez = az >= floor_d ? Fp<Real>::fabs(t.noi.z) : Real(0);
+	// quantised planes reach kQMax steps from the centre: q * qscale rounds like a term of that size
+	Real ex = ax >= floor_d ? Fp<Real>::fmax(Fp<Real>::fabs(t.noi.x), reach * Real(kQMax) * Fp<Real>::fabs(t.qscale.x)) : Real(0);
+	Real ey = ay >= floor_d ? Fp<Real>::fmax(Fp<Real>::fabs(t.noi.y), reach * Real(kQMax) * Fp<Real>::fabs(t.qscale.y)) : Real(0);
+	Real ez = az >= floor_d ? Fp<Real>::fmax(Fp<Real>::fabs(t.noi.z), reach * Real(kQMax) * Fp<Real>::fabs(t.qscale.z)) : Real(0);
 	t.eps = Fp<Real>::fmax(Fp<Real>::fmax(ex, ey), ez) * Real(0x1p-21);
 	t.rcp_a = Fp<Real>::rcp(dot(r.d, r.d));
 	return t;
@@ -332,18 +348,24 @@ RT_FN bool hit_cube(const Prim<Real>& c, const TravRay<Real>& r, Real* t) {
 // min3/max3 chains; its rounding is absolute (an ulp of |o * inv|), so the far side gets the
 // relative pad 2^-18 plus the ray's absolute slack eps (see prepare()).  A NaN plane distance
 // drops out of min/max, which only makes the test more permissive.
+// The fused f32 form on explicit operands: t = plane * scale + offset per axis.  For full nodes
+// scale = 1/d and offset = -o/d; for quantised nodes the planes are grid steps and
+// scale = step/d, offset = -(o - centre)/d.
+__device__ __forceinline__ bool hit_box_fused(const float* b, V3<float> scale, V3<float> offset, float eps, float best_t, float* entry) {
+	// One v_fma_f32 per plane.  (The two-wide v_pk_fma_f32 halves the instruction count here but
+	// measured 2-4 % slower in this divergent loop.)
+	float x0 = __builtin_fmaf(b[kBoxLoX], scale.x, offset.x), x1 = __builtin_fmaf(b[kBoxHiX], scale.x, offset.x);
+	float y0 = __builtin_fmaf(b[kBoxLoY], scale.y, offset.y), y1 = __builtin_fmaf(b[kBoxHiY], scale.y, offset.y);
+	float z0 = __builtin_fmaf(b[kBoxLoZ], scale.z, offset.z), z1 = __builtin_fmaf(b[kBoxHiZ], scale.z, offset.z);
+	float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(x0, x1), Fp<float>::fmin(y0, y1)), Fp<float>::fmin(z0, z1));
+	float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(x0, x1), Fp<float>::fmax(y0, y1)),
+	                             Fp<float>::fmin(Fp<float>::fmax(z0, z1), best_t));
+	*entry = tnear;
+	return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, eps);
+}
 RT_FN bool hit_box(const Real* b, const TravRay<Real>& r, Real best_t, Real* entry) {
 	if constexpr (std::is_same<Real, float>::value && RT_FUSED_BOX) {
-		// One v_fma_f32 per plane.  (The two-wide v_pk_fma_f32 halves the instruction count here but
-		// measured 2-4 % slower in this divergent loop.)
-		float x0 = __builtin_fmaf(b[kBoxLoX], r.inv.x, r.noi.x), x1 = __builtin_fmaf(b[kBoxHiX], r.inv.x, r.noi.x);
-		float y0 = __builtin_fmaf(b[kBoxLoY], r.inv.y, r.noi.y), y1 = __builtin_fmaf(b[kBoxHiY], r.inv.y, r.noi.y);
-		float z0 = __builtin_fmaf(b[kBoxLoZ], r.inv.z, r.noi.z), z1 = __builtin_fmaf(b[kBoxHiZ], r.inv.z, r.noi.z);
-		float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(x0, x1), Fp<float>::fmin(y0, y1)), Fp<float>::fmin(z0, z1));
-		float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(x0, x1), Fp<float>::fmax(y0, y1)),
-		                             Fp<float>::fmin(Fp<float>::fmax(z0, z1), best_t));
-		*entry = tnear;
-		return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, r.eps);
+		return hit_box_fused(b, r.inv, r.noi, r.eps, best_t, entry);
 	} else {
 		Real tx0 = (b[kBoxLoX] - r.o.x) * r.inv.x, tx1 = (b[kBoxHiX] - r.o.x) * r.inv.x;
 		Real ty0 = (b[kBoxLoY] - r.o.y) * r.inv.y, ty1 = (b[kBoxHiY] - r.o.y) * r.inv.y;
@@ -448,6 +470,40 @@ __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& 
 			tv.cur = cr;
 		} else {
 			trav_pop<Real, kThreads>(tv, stack);
+		}
+	}
+}
+// The same descent over quantised nodes (f32 trees in global memory): two 16-byte loads per
+// visit instead of four, twelve conversions more.
+template <int kThreads, bool kCount>
+__device__ __forceinline__ void trav_inner_q(Trav<float>& tv, const TravRay<float>& r, const QNode* nodes, int* stack, Tally& tally, Regions& rg,
+                                             int32_t inner_exit) {
+	const int32_t entered = (int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit;
+	while (tv.cur >= 0) {
+		if ((int32_t)__popcll(__ballot(1)) * 16 < entered) break;
+		region_tick<kCount>(rg, kRegInner);
+		const uint4* p = reinterpret_cast<const uint4*>(nodes + tv.cur);
+		const uint4 a = p[0], b = p[1];
+		auto lo16 = [](uint32_t w) { return (float)(int16_t)(uint16_t)(w & 0xffffu); };
+		auto hi16 = [](uint32_t w) { return (float)((int32_t)w >> 16); };
+		const float pl[12] = {lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z),
+		                      lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y)};
+		float el, er;
+		bool hl = hit_box_fused(pl, r.qscale, r.noi, r.eps, tv.best_t, &el);
+		bool hr = hit_box_fused(pl + 6, r.qscale, r.noi, r.eps, tv.best_t, &er);
+		int32_t cl = (int32_t)b.z, cr = (int32_t)b.w;
+		if (kCount) tally.box += 2;
+		if (hl && hr) {
+			bool right_first = er < el;
+			stack[tv.sp * kThreads] = right_first ? cl : cr;
+			tv.sp++;
+			tv.cur = right_first ? cr : cl;
+		} else if (hl) {
+			tv.cur = cl;
+		} else if (hr) {
+			tv.cur = cr;
+		} else {
+			trav_pop<float, kThreads>(tv, stack);
 		}
 	}
 }
@@ -646,8 +702,9 @@ enum : int { kIdle = 0, kTraverse = 1, kShade = 2, kFresh = 3 };
 // ---------------------------------------------------------------------------------------
 // The megakernel.
 // ---------------------------------------------------------------------------------------
-template <typename Real, int kThreads, bool kLds, bool kCount>
+template <typename Real, int kThreads, bool kLds, bool kCount, bool kQ = false>
 __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? (kThreads == 1024 ? 8 : RT_MINWAVES) : 2)) void render_kernel(RenderArgs<Real> A) {
+	static_assert(!kQ || (!kLds && std::is_same<Real, float>::value), "quantised nodes: f32 trees in global memory only");
 	extern __shared__ __align__(64) char smem[];
 	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kThreads]
 	const uint32_t stack_bytes = (uint32_t)A.stack_entries * kThreads * 4u;
@@ -686,7 +743,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	tv.cur = kDone; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
 	rng.state = 0; rng.inc = 1;
 	T = L = mk<Real>(0, 0, 0);
-	ray.o = ray.d = ray.inv = ray.noi = T; ray.eps = ray.rcp_a = 0;
+	ray.o = ray.d = ray.inv = ray.noi = ray.qscale = T; ray.eps = ray.rcp_a = 0;
 
 	// wave state (uniform)
 	// Work items are cut into kQueues contiguous ranges (bands of the image), each with its own
@@ -770,8 +827,18 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 		if (__ballot(state != kIdle) == 0ull) break;
 		// rays made above by shading (next bounce) and by regeneration (camera rays) are set up together
 		if (state == kFresh) {
-			ray = prepare<Real>(RayT<Real>{ray.o, ray.d});
 			trav_begin<Real>(tv);
+			if constexpr (kQ) {
+				ray = prepare<Real>(RayT<Real>{ray.o, ray.d}, &A.qframe);
+				tv.cur = A.qframe.start;
+				if (A.qframe.big_leaf != 0) {  // the oversized primitives first, the tree after them
+					stack[0] = A.qframe.start;
+					tv.sp = 1;
+					tv.cur = A.qframe.big_leaf;
+				}
+			} else {
+				ray = prepare<Real>(RayT<Real>{ray.o, ray.d});
+			}
 			state = kTraverse;
 		}
 
@@ -788,7 +855,8 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			}
 			if (state == kTraverse) {
 				region_tick<kCount>(rg, kRegTravRound);
-				trav_inner<Real, kThreads, kCount>(tv, ray, nodes, stack, tally, rg, A.inner_exit);
+				if constexpr (kQ) trav_inner_q<kThreads, kCount>(tv, ray, reinterpret_cast<const QNode*>(A.scene + A.qnodes_off), stack, tally, rg, A.inner_exit);
+				else trav_inner<Real, kThreads, kCount>(tv, ray, nodes, stack, tally, rg, A.inner_exit);
 				if (tv.cur < 0 && tv.cur != kDone) trav_leaf<Real, kThreads, kCount>(tv, ray, prims, gates, stack, tally, rg);
 				if (tv.cur == kDone) state = kShade;
 			}

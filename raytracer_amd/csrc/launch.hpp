@@ -14,6 +14,7 @@ struct LaunchCfg {
 	size_t dyn_lds;      // bytes of dynamic LDS
 	bool scene_in_lds;
 	bool count;          // instrumented (box / sphere / cube test counters)
+	bool quantised;      // f32, scene in global memory: traverse the 32-byte quantised nodes
 };
 
 hipError_t launch_render(const RenderArgs<float>& a, const LaunchCfg& cfg, hipStream_t s);

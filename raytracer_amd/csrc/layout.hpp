@@ -36,6 +36,22 @@ struct alignas(sizeof(Real) * 16) Node {
 	int32_t child[2];  // left, right
 };
 static_assert(sizeof(Node<float>) == 64, "f32 node is one 64-byte line");
+
+// Half-size node for f32 trees that live in global memory, where a node visit costs one L1
+// access per 16 bytes per lane: the twelve planes as signed 16-bit steps of a scene-wide grid
+// (QFrame: plane = centre + q * step per axis), rounded outward by at least one step, so every
+// box contains the box it stands for and the closest hit is unchanged.  Two 16-byte loads.
+struct alignas(32) QNode {
+	int16_t q[12];     // same plane order as Node::box
+	int32_t child[2];
+};
+static_assert(sizeof(QNode) == 32, "quantised node is 32 bytes");
+struct QFrame {
+	float centre[3], step[3];
+	int32_t start;     // where traversal begins: an inner node of the quantised array, or a leaf code
+	int32_t big_leaf;  // leaf of oversized primitives tested before the tree, 0 = none
+};
+constexpr int kQMax = 32767;
 static_assert(sizeof(Node<double>) == 128, "f64 node is 128 bytes");
 
 // Sphere: v = centre.xyz, radius, gate word (see Gate), 0.

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void wf_extend(WfArgs<Real> A) {
 	Tally tally{0, 0, 0};
 	Regions rg{};
 	tv.cur = kDone; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
-	ray.o = ray.d = ray.inv = ray.noi = mk<Real>(0, 0, 0); ray.eps = ray.rcp_a = 0;
+	ray.o = ray.d = ray.inv = ray.noi = ray.qscale = mk<Real>(0, 0, 0); ray.eps = ray.rcp_a = 0;
 	uint32_t pool_pos = 0, pool_end = 0;
 	bool dry = false;
 

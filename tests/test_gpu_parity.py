@@ -393,3 +393,26 @@ def test_checkpoint_resume_is_bit_identical(rt, renderers, tmp_path):
 def _quantize_like_reference(v):   # raytracer_headless/src/main.rs:6-12: (v * 255.0) as u8
     x = np.nan_to_num(v * 255.0, nan=0.0, posinf=255.0, neginf=0.0)
     return np.clip(np.trunc(x), 0, 255).astype(np.uint8)
+
+
+def test_quantised_nodes_change_no_path(rt):
+    """Large f32 scenes are traversed over 32-byte quantised nodes whose boxes contain the full
+    boxes, with the oversized primitives in a leaf of their own: the primitive tests, and so
+    every path, must come out bit for bit as over the full nodes."""
+    import os
+    sc = rt.create_synthetic_scene(60_000, seed=5)
+    cam = rt.Camera((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0, 160, 90)
+    r = rt.Renderer(sc, cam, max_depth=12, seed=3)
+    try:
+        os.environ["RTHIP_COUNT"] = "1"
+        os.environ["RTHIP_QNODES"] = "0"
+        full = r.render_samples(3, precision=rt.F32); c_full = r.stats()
+        os.environ["RTHIP_QNODES"] = "1"
+        quant = r.render_samples(3, precision=rt.F32); c_q = r.stats()
+    finally:
+        os.environ.pop("RTHIP_QNODES", None); os.environ.pop("RTHIP_COUNT", None)
+    assert c_q["scene_in_lds"] == 0 and c_q["rays"] == c_full["rays"]
+    assert np.array_equal(full, quant)
+    # the coarser boxes cost a few extra tests, skipping the root's node saves two per ray
+    assert 0.9 * c_full["box_tests"] <= c_q["box_tests"] <= 1.3 * c_full["box_tests"]
+    r.close()
