@@ -181,8 +181,8 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	uint64_t want_blocks = (n_items + waves_per_block - 1) / waves_per_block;
 	plan->cfg.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc * c->num_cu, want_blocks));
 	// Leave the traversal loop for shading / regeneration once this few lanes are still in it.
-	// Measured optimum: 12-16 with the scene in LDS, about 32 when every node is a trip to L2.
-	plan->threshold = env_int("RTHIP_TRAV_THRESHOLD", in_lds ? 14 : 32);
+	// Measured optimum: 12-16 with the scene in LDS, about 36 when every node is a trip to L1 or L2.
+	plan->threshold = env_int("RTHIP_TRAV_THRESHOLD", in_lds ? 14 : 36);
 	return RTHIP_OK;
 }
 
