@@ -155,7 +155,7 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 		size_t lds = (size_t)c->tree_depth * threads * 4 + (in_lds ? blob.lds_bytes : 0);
 		int b = 0;
 		if (wavefront) HIP_TRY(c, f64 ? wf_extend_blocks_per_cu_f64(threads, in_lds, lds, &b) : wf_extend_blocks_per_cu_f32(threads, in_lds, lds, &b));
-		else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, in_lds, lds, &b) : render_blocks_per_cu_f32(threads, in_lds, lds, &b));
+		else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, in_lds, lds, &b) : render_blocks_per_cu_f32(threads, in_lds, lds, &b, plan->cfg.quantised));
 		if (b * threads / 64 > best_waves) {
 			best_waves = b * threads / 64; bpc = b;
 			plan->cfg.threads = threads; plan->cfg.dyn_lds = lds;

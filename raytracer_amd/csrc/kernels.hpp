@@ -40,6 +40,9 @@ namespace rthip {
 #ifndef RT_FUSED_BOX
 #define RT_FUSED_BOX 1
 #endif
+#ifndef RT_QWAVES
+#define RT_QWAVES 7   // the global-memory variant is latency bound: one more wave per SIMD (72 VGPRs)
+#endif
 #ifndef RT_MINWAVES
 #define RT_MINWAVES 6
 #endif
@@ -703,7 +706,7 @@ enum : int { kIdle = 0, kTraverse = 1, kShade = 2, kFresh = 3 };
 // The megakernel.
 // ---------------------------------------------------------------------------------------
 template <typename Real, int kThreads, bool kLds, bool kCount, bool kQ = false>
-__global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? (kThreads == 1024 ? 8 : RT_MINWAVES) : 2)) void render_kernel(RenderArgs<Real> A) {
+__global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? (kThreads == 1024 ? 8 : (kQ ? RT_QWAVES : RT_MINWAVES)) : 2)) void render_kernel(RenderArgs<Real> A) {
 	static_assert(!kQ || (!kLds && std::is_same<Real, float>::value), "quantised nodes: f32 trees in global memory only");
 	extern __shared__ __align__(64) char smem[];
 	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kThreads]

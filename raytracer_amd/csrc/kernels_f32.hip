@@ -41,7 +41,7 @@ hipError_t launch_finalize(const unsigned long long* accum, void* out, int width
 }
 
 hipError_t wf_extend_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks) { return wf_extend_blocks_per_cu_impl(threads, scene_in_lds, dyn_lds, blocks); }
-hipError_t render_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks) { return blocks_per_cu_impl(threads, scene_in_lds, dyn_lds, blocks); }
+hipError_t render_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks, bool quantised) { return blocks_per_cu_impl(threads, scene_in_lds, dyn_lds, blocks, quantised); }
 
 hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x, hipStream_t s) {
 	unsigned n = (unsigned)width * (unsigned)height;

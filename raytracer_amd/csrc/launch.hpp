@@ -22,7 +22,7 @@ hipError_t launch_render(const RenderArgs<double>& a, const LaunchCfg& cfg, hipS
 hipError_t launch_probe(const ProbeArgs<float>& a, size_t dyn_lds, hipStream_t s);
 hipError_t launch_probe(const ProbeArgs<double>& a, size_t dyn_lds, hipStream_t s);
 // Resident workgroups per CU for the render kernel at this much dynamic LDS.
-hipError_t render_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks);
+hipError_t render_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks, bool quantised = false);
 hipError_t render_blocks_per_cu_f64(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks);
 // Accumulation buffer (tile-major fixed point) -> row-major [H][W][3] doubles (sums).
 hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x, hipStream_t s);
