@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -353,6 +355,7 @@ struct Builder {
 	}
 
 	// ---- reference tree: src/bvh.rs:17-81 ------------------------------------------------
+	std::vector<std::pair<double, int32_t>> sort_keys;  // scratch of ref_build
 	int ref_build(size_t begin, size_t end) {
 		size_t len = end - begin;
 		// :28-47: the axis of largest extent of the cached boxes; the first such axis on ties
@@ -370,9 +373,15 @@ struct Builder {
 		}
 		// :18-26,49: ascending by min+max on that axis.  Equal keys keep their current order
 		// (the reference's unstable sort leaves it unspecified).
-		std::stable_sort(order.begin() + (long)begin, order.begin() + (long)end, [this, axis](int32_t a, int32_t b) {
-			return (ref_min(a, axis) + ref_max(a, axis)) < (ref_min(b, axis) + ref_max(b, axis));
-		});
+		// (keys are gathered once per range: the sort then compares adjacent doubles instead of
+		// chasing object records, which is what the build of a million objects spends its time on)
+		sort_keys.resize(len);
+		for (size_t i = 0; i < len; i++) {
+			int32_t id = order[begin + i];
+			sort_keys[i] = {ref_min(id, axis) + ref_max(id, axis), id};
+		}
+		std::stable_sort(sort_keys.begin(), sort_keys.end(), [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) { return a.first < b.first; });
+		for (size_t i = 0; i < len; i++) order[begin + i] = sort_keys[i].second;
 		int me = (int)ref_nodes.size();
 		ref_nodes.push_back(RefNode{begin, end, -1, -1, empty_box()});
 		if (len < 6) {  // :52-61
@@ -650,8 +659,17 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		out->mats64[(size_t)i].param = objs[i].param;
 		out->mats32[(size_t)i].param = (float)objs[i].param;
 	}
+	const bool timing = std::getenv("RTHIP_BUILD_TIMING") != nullptr;
+	auto t_start = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if (!timing) return;
+		auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "[rthip build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_start).count());
+		t_start = now;
+	};
 	// 1. the reference's tree: ranks, leaf order, gates
 	int ref_root = b.ref_build(0, (size_t)n);
+	lap("reference tree");
 	{
 		std::vector<int> chain;
 		int32_t next_rank = 0;
@@ -670,6 +688,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		}
 		out->ref_depth = d;
 	}
+	lap("ranks, gates, depth");
 	// 2. the device tree
 	const char* mode = std::getenv("RTHIP_TREE");
 	bool use_sah = !(mode && std::string(mode) == "ref");
@@ -741,6 +760,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 			b.shape_ref(ref_root, 0);
 		}
 	}
+	lap("device tree");
 	out->depth = std::max(1, b.max_depth);
 	if (out->depth > kStackMax) { *err = "tree deeper than the traversal stack"; return false; }
 	// 3. large scenes: the quantised copy of the f32 nodes (see QNode).  The grid spans the boxes
