@@ -226,7 +226,7 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 	const SceneBlob& blob = std::is_same<Real, double>::value ? c->blob64 : c->blob32;
 	const uint64_t per_item = (uint64_t)kTilePixels * plan.chunk;
 	const uint64_t total = (uint64_t)plan.n_items * per_item;
-	uint64_t batch = (uint64_t)std::max(1, env_int("RTHIP_WF_BATCH", 8 << 20));
+	uint64_t batch = (uint64_t)std::max(1, env_int("RTHIP_WF_BATCH", 64 << 20));
 	batch = std::min<uint64_t>(std::max<uint64_t>(batch, per_item), std::max<uint64_t>(total, 1));
 	if (batch > 0xFFFFFF00ull) batch = 0xFFFFFF00ull;
 	// carve the state memory: two states (3 quads + meta + slot) and the hit records
