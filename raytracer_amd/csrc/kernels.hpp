@@ -214,8 +214,7 @@ RT_FN RayT<Real> camera_ray(const CameraT<Real>& c, Real x, Real y, Rng& rng, bo
 
 // src/scene.rs:116-120, and the wallpaper sky (formula of
 // raytracer_gpu/src/shaders/compute.wgsl:186-195 on the normalised direction).
-RT_FN V3<Real> sky(V3<Real> dir, int sky_mode) {
-	V3<Real> u = normalize(dir);
+RT_FN V3<Real> sky(V3<Real> u, int sky_mode) {  // u = the normalised direction
 	if (sky_mode == RTHIP_SKY_WALLPAPER) {
 		Real strength = Real(0.5) * (-u.y + Real(0.25));
 		Real t = Real(0.5) * (u.x + Real(1));
@@ -593,10 +592,9 @@ template <typename Real> struct Scattered {
 // Material::scatter, src/materials.rs:17-68.  ok = false for None (an absorbed metal ray).
 // Draw counts: Lambertian 3, Metal 3 (also when fuzz is 0), Dielectric 1 unless total
 // internal reflection (the `||` of :54-55 short-circuits).
-RT_FN Scattered<Real> scatter(const Hit<Real>& h, const Mat<Real>& m, V3<Real> dir_in, Rng& rng) {
+RT_FN Scattered<Real> scatter(const Hit<Real>& h, const Mat<Real>& m, V3<Real> unit_dir, Rng& rng) {  // unit_dir = normalize(ray direction)
 	Scattered<Real> out;
 	out.ok = true;
-	const V3<Real> unit_dir = normalize(dir_in);  // metal and glass use it; computed once for the wave
 	if (h.material != RTHIP_DIELECTRIC) {
 		// Lambertian: n + ruv (near-zero -> n).  Metal: reflect(unit_dir, n) + fuzz * ruv, absorbed when it
 		// points into the surface.  Both draw one random unit vector, so the lanes of either kind share one
@@ -659,14 +657,16 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 // Returns true when the path continues along *next.
 RT_FN bool shade_ray(const TravRay<Real>& ray, Real best_t, int32_t best_prim, const Prim<Real>* prims, const Mat<Real>* mats,
                      int sky_mode, Rng& rng, V3<Real>& T, V3<Real>& L, int32_t& depth, RayT<Real>* next) {
+	const V3<Real> unit_dir = normalize(ray.d);  // sky, metal and glass all start from it: once per wave
 	if (best_prim < 0) {
-		L = L + T * (sky<Real>(ray.d, sky_mode) * T);
+		L = L + T * (sky<Real>(unit_dir, sky_mode) * T);
 		return false;
 	}
 	const Prim<Real>& pr = prims[best_prim];
+	// the material record comes from global memory: ask for it before the hit record is worked out
+	const Mat<Real> mat = mats[pr.id & ((1 << kMatShift) - 1)];
 	Hit<Real> h = make_hit<Real>(pr, ((pr.id >> kKindShift) & 1) == RTHIP_SPHERE, ray, best_t);
-	const Mat<Real>& mat = mats[h.id];
-	Scattered<Real> sc = scatter<Real>(h, mat, ray.d, rng);
+	Scattered<Real> sc = scatter<Real>(h, mat, unit_dir, rng);
 	if (!sc.ok) return false;
 	if (h.material == RTHIP_LAMBERTIAN) L = L + T * (ld3(mat.albedo) * mat.param);  // materials.rs:71-77
 	T = T * sc.att;
