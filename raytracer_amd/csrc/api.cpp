@@ -445,7 +445,8 @@ int32_t rthip_render_accumulate_async(rthip_ctx* c, const rthip_render_params* p
 	int32_t rc = validate(c, p);
 	if (rc != RTHIP_OK) return rc;
 	HIP_TRY(c, hipSetDevice(c->device));
-	if ((rc = collect_stats(c)) != RTHIP_OK) return rc;  // the control block is reused per launch
+	// No wait for the previous launch: the control block (work counters, statistics) is cleared and
+	// used in stream order, so launches queue up back to back; statistics are those of the last one.
 	if ((rc = ensure_accum(c)) != RTHIP_OK) return rc;
 	bool count = env_int("RTHIP_COUNT", 0) != 0;
 	if (p->variant == RTHIP_WAVEFRONT) {
