@@ -7,7 +7,7 @@
 //
 // One bounce = extend + shade.  Live paths are kept DENSE: shade writes the survivors of
 // bounce b to the other half of a ping-pong state buffer at positions handed out by a
-// wave-level ballot/prefix (one atomic per wave), so every stage reads and writes its state
+// ballot/prefix over the workgroup (one atomic per 1024 paths), so every stage reads and writes its state
 // coalesced and a wave always starts a stage with 64 live rays, however divergent the
 // paths' lengths are (depth 50 leaves long thin tails that this regrouping keeps packed).
 // extend is itself persistent: a lane whose ray is done pulls the next ray of the wave's
