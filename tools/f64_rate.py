@@ -1,5 +1,6 @@
 """Throughput of the f64 parity mode (the reference's own arithmetic on the GPU) on both bench scenes."""
-import sys; sys.path.insert(0, "/root/repo")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 for which, scene, depth in (("cfg2", "default", 10), ("cfg3", "sample", 50)):
