@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per GPU per step")
+    ap.add_argument("--split", default="spp", choices=["spp", "tile"],
+                    help="N > 1: spp = every GPU renders its own samples of the full frame (weak scaling, the default); "
+                         "tile = every GPU renders all samples of its own 8x8 tiles (strong scaling)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 / 1-spp frame extras")
     args = ap.parse_args()
@@ -145,13 +148,15 @@ def main():
         stream = torch.cuda.current_stream(device)
         r.set_stream(stream.cuda_stream)
         pipe = D.MergePipeline(lambda: D.new_accum_tensor(wl["width"], wl["height"], device), dst=0)
-        begin = rank * wl["spp"]  # weak scaling: every rank renders its own samples of the full frame
+        tile_split = args.split == "tile" and world > 1
+        begin = 0 if tile_split else rank * wl["spp"]  # spp split: every rank renders its own samples of the full frame
+        part = D.tile_part(rank, world) if tile_split else (0, 1)
 
         def step():
             accum = pipe.acquire()   # the other buffer may still be in its reduce
             accum.zero_()
             r.set_accum_buffer(accum.data_ptr(), accum.numel())
-            r.accumulate(wl["spp"], spp_begin=begin, sync=False)
+            r.accumulate(wl["spp"], part=part, spp_begin=begin, sync=False)
             pipe.release()           # one RCCL reduce per frame, overlapped with the next frame's tracing
 
         for _ in range(warmup):
@@ -195,17 +200,19 @@ def main():
 
     res = run_workload(args.workload, args.steps, args.warmup, args.spp)
     wl = res["wl"]
-    paths_per_step_all = wl["width"] * wl["height"] * wl["spp"] * world
+    tile_split = args.split == "tile" and world > 1
+    paths_per_step_all = wl["width"] * wl["height"] * wl["spp"] * (1 if tile_split else world)
     value = paths_per_step_all * args.steps / res["elapsed"] / 1e6
 
     if rank == 0:
         line = {
             "metric": "Mpaths/s (path-tracing throughput, 1080p)", "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["elapsed"] / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["desc"], "spp_per_gpu_per_step": wl["spp"], "split": "spp (each GPU renders its own samples of the full frame; one RCCL reduce merges)",
+            "higher_is_better": True, "scaling": "strong" if tile_split else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "spp_per_gpu_per_step": wl["spp"], "split": ("tile (each GPU renders all samples of its own 8x8 tiles; one RCCL reduce merges)" if tile_split else
+                                 "spp (each GPU renders its own samples of the full frame; one RCCL reduce merges)"),
                        "scene_objects": int(len(res["scene"])), "tree_depth": res["stats"]["tree_depth"], "scene_in_lds": res["stats"]["scene_in_lds"]},
-            "mrays_per_s": res["rays"] * world * args.steps / res["elapsed"] / 1e6 if res["kernel_ms"] else None,
+            "mrays_per_s": res["rays"] * world * args.steps / res["elapsed"] / 1e6 if res["kernel_ms"] else None,  # rank 0's rays x ranks
             "rays_per_path": res["rays"] / max(1, res["paths"]),
         }
         if "frame_ms_1spp" in res:
