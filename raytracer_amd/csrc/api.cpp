@@ -178,6 +178,10 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	if (n_items > 0xFFFFFF00ull) return fail(c, RTHIP_ERR_LIMIT, "too many work items in one call: lower spp_count");
 	plan->chunk = chunk; plan->n_chunks = n_chunks; plan->n_items = (uint32_t)n_items;
 	uint64_t waves_per_block = (uint64_t)plan->cfg.threads / 64;
+	// Short launches (a viewer's 1-spp frame: ~340 paths per resident wave) are all start-up and
+	// tail; two thirds of the resident workgroups finish them 10 % sooner.
+	const uint64_t my_paths = n_items * kTilePixels * chunk;
+	if (cap <= 0 && bpc >= 3 && my_paths < 512ull * (uint64_t)bpc * c->num_cu * waves_per_block) bpc = bpc * 2 / 3;
 	uint64_t want_blocks = (n_items + waves_per_block - 1) / waves_per_block;
 	plan->cfg.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc * c->num_cu, want_blocks));
 	// Leave the traversal loop for shading / regeneration once this few lanes are still in it.
