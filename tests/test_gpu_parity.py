@@ -416,3 +416,47 @@ def test_quantised_nodes_change_no_path(rt):
     # the coarser boxes cost a few extra tests, skipping the root's node saves two per ray
     assert 0.9 * c_full["box_tests"] <= c_q["box_tests"] <= 1.3 * c_full["box_tests"]
     r.close()
+
+
+def test_axis_aligned_camera_rays(rt, oracle, monkeypatch):
+    """A camera looking straight down an axis over axis-aligned cubes: the centre column and row
+    of an odd-sized frame have direction components of exactly zero.  There the reference's cube
+    formula (src/shapes/cube.rs:26-33) turns inf - inf into NaN, which max() drops: the cube
+    counts as hit on that axis wherever it lies, and whether the reference finds such a phantom
+    depends on which boxes of ITS tree lie above the cube.  So for exactly axis-parallel rays,
+    and only for them, the closest hit depends on the tree: the f64 path is bit-exact on the
+    reference-shaped tree, and on the default tree everywhere except on those rays.  (f32 tests
+    cubes as plane distances and has no phantoms; jittered rays are never axis-parallel.)"""
+    s = rt.Scene()
+    g = np.random.default_rng(11)
+    for i in range(-3, 4):
+        for j in range(-3, 4):
+            s.add_cube((float(i), float(j), 5.0 + float(g.integers(0, 3))), (0.5, 0.5, 0.5), rt.Material.lambertian((0.5, 0.5, 0.5), 0.0))
+            s.add_sphere((float(i), float(j), 3.0), 0.25, rt.Material.metal((0.8, 0.8, 0.8), 0.0))
+    s.add_cube((0.0, 0.0, 20.0), (50.0, 50.0, 1.0), rt.Material.lambertian((0.3, 0.3, 0.3), 0.0))
+    cam = ((0.0, 0.0, -10.0), (0.0, 0.0, 1.0), 40.0, 10.0, 0.0, 65, 49)
+    osc = oracle.OracleScene(s.objects)
+    desc = oracle.camera_desc(*cam)
+    ref = osc.trace_primary(desc, oracle.TIGHT, jitter=False, seed=1, sample=0)
+    fa = osc.trace_primary(desc, oracle.FAITHFUL, jitter=False, seed=1, sample=0)
+    _, dirs = oracle.camera_rays(desc, seed=1, sample=0, jitter=False)
+    parallel = (dirs == 0.0).any(axis=-1)
+    assert parallel.any(), "the frame should contain exactly axis-parallel rays"
+    for a, b in zip(ref, fa):
+        assert np.array_equal(a, b)
+    # default (surface-area) tree: exact except, possibly, on the axis-parallel rays
+    r = rt.Renderer(s, rt.Camera(*cam), seed=1, precision=rt.F64)
+    got = r.trace_primary(rt.F64)
+    assert not (got[0] != ref[0])[~parallel].any() and np.array_equal(got[1][~parallel], ref[1][~parallel])
+    g32 = r.trace_primary(rt.F32)
+    assert (g32[0] != ref[0])[~parallel].mean() <= 2e-3
+    same = ~parallel & (g32[0] == ref[0]) & (ref[0] >= 0)
+    assert same.mean() > 0.8 and np.allclose(g32[1][same], ref[1][same], rtol=1e-5)
+    r.close()
+    # reference-shaped tree: exact everywhere, phantoms included
+    monkeypatch.setenv("RTHIP_TREE", "ref")
+    r = rt.Renderer(s, rt.Camera(*cam), seed=1, precision=rt.F64, max_depth=6)
+    got = r.trace_primary(rt.F64)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    r.close()
