@@ -9,7 +9,7 @@ for which, scene, depth in (("cfg2", "default", 10), ("cfg3", "sample", 50)):
     r = None
     for v in vals:
         os.environ[name] = v
-        if r is None or name.startswith(("RTHIP_SAH", "RTHIP_TREE")):  # read at scene upload
+        if r is None or name.startswith(("RTHIP_SAH", "RTHIP_TREE", "RTHIP_BIG")):  # read at scene upload
             if r is not None:
                 r.close()
             r = rt.Renderer(rt.Scene.generate(scene), rt.Camera(*CAM, 1920, 1080), max_depth=depth, seed=1)
