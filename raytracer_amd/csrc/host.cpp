@@ -697,67 +697,111 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	if (const char* v = std::getenv("RTHIP_SAH_CPRIM")) b.cost_prim = std::atof(v);
 	if (const char* v = std::getenv("RTHIP_SAH_SWEEP")) b.sweep_max = std::atoi(v);
 	bool big_ids_empty = true;
-	int32_t root = b.new_node();  // node 0 is the root
+	int32_t root = 0;
 	Builder::Sub l, r;
 	r.code = leaf_code(0, 0, 0);
 	r.b64 = r.b32 = empty_box();
 	if (use_sah) {
-		for (int64_t i = 0; i < n; i++) {
-			if (!b.can_be_hit((int32_t)i)) continue;
-			Builder::Item it;
-			it.id = (int32_t)i;
-			it.b = b.bounds64((int32_t)i);
-			for (int k = 0; k < 3; k++) it.c[k] = 0.5 * (it.b.lo[k] + it.b.hi[k]);
-			b.items.push_back(it);
-		}
-		size_t m = b.items.size();
-		// Small scenes afford the exact sweep everywhere (+3 % on a 500-object scene).  On a million
-		// objects it costs a second of build time and a level of depth (the traversal stack is LDS
-		// that resident waves pay for) without tracing faster.
-		if (m <= 65536 && !std::getenv("RTHIP_SAH_SWEEP")) b.sweep_max = 4096;
-		// A few primitives that dwarf the rest (a ground slab, a sun) would stretch the box of every
-		// node above them.  They go into one leaf of their own, the left child of the root, and the
-		// surface-area build runs over the rest (its root is the right child).  Measured: +2.5 % on
-		// the 500-object scenes, +4 % on the million-object one.
-		std::vector<int32_t> big;
-		const char* big_min = std::getenv("RTHIP_BIG_LEAF_MIN");
-		if (m > (size_t)(big_min ? std::atoi(big_min) : 32) && !std::getenv("RTHIP_NO_BIG_LEAF")) {
-			auto diag = [](const Builder::Item& it) {
-				double dx = it.b.hi[0] - it.b.lo[0], dy = it.b.hi[1] - it.b.lo[1], dz = it.b.hi[2] - it.b.lo[2];
-				return std::sqrt(dx * dx + dy * dy + dz * dz);
-			};
-			std::vector<double> d(m);
-			for (size_t i = 0; i < m; i++) d[i] = diag(b.items[i]);
-			std::nth_element(d.begin(), d.begin() + (long)(m / 2), d.end());
-			const double limit = 64.0 * d[m / 2];
-			int ns = 0, nc = 0;
-			for (size_t i = 0; i < m; i++)
-				if (diag(b.items[i]) > limit) { big.push_back(b.items[i].id); (objs[b.items[i].id].kind == RTHIP_SPHERE ? ns : nc)++; }
-			if (big.empty() || ns > 7 || nc > 7) {
-				big.clear();  // none, or more than one leaf code can hold: leave the tree as it is
-			} else {
-				b.items.erase(std::remove_if(b.items.begin(), b.items.end(), [&](const Builder::Item& it) { return diag(it) > limit; }), b.items.end());
-				m = b.items.size();
+		auto attempt = [&](double cost_prim) {
+			out->nodes64.clear(); out->nodes32.clear(); out->prims64.clear(); out->prims32.clear();
+			b.items.clear();
+			b.max_depth = 0;
+			b.cost_prim = cost_prim;
+			big_ids_empty = true;
+			l = Builder::Sub();
+			root = b.new_node();  // node 0 is the root
+			for (int64_t i = 0; i < n; i++) {
+				if (!b.can_be_hit((int32_t)i)) continue;
+				Builder::Item it;
+				it.id = (int32_t)i;
+				it.b = b.bounds64((int32_t)i);
+				for (int k = 0; k < 3; k++) it.c[k] = 0.5 * (it.b.lo[k] + it.b.hi[k]);
+				b.items.push_back(it);
 			}
-		}
-		big_ids_empty = big.empty();
-		if (!big.empty()) {
-			Builder::Sub bl = b.emit_leaf(big.data(), (int)big.size());  // node 0 is already reserved for the root
-			Builder::Sub rest = b.sah_build(0, m, 1);
-			b.write_node(root, bl, rest);
-			if (b.max_depth < 1) b.max_depth = 1;
-		} else if (m <= (size_t)b.max_leaf) {
-			l = m ? b.sah_leaf(0, m) : r;
+			size_t m = b.items.size();
+			// Small scenes afford the exact sweep everywhere (+3 % on a 500-object scene).  On a million
+			// objects it costs a second of build time and a level of depth (the traversal stack is LDS
+			// that resident waves pay for) without tracing faster.
+			if (m <= 65536 && !std::getenv("RTHIP_SAH_SWEEP")) b.sweep_max = 4096;
+			// A few primitives that dwarf the rest (a ground slab, a sun) would stretch the box of every
+			// node above them.  They go into one leaf of their own, the left child of the root, and the
+			// surface-area build runs over the rest (its root is the right child).  Measured: +2.5 % on
+			// the 500-object scenes, +4 % on the million-object one.
+			std::vector<int32_t> big;
+			const char* big_min = std::getenv("RTHIP_BIG_LEAF_MIN");
+			if (m > (size_t)(big_min ? std::atoi(big_min) : 32) && !std::getenv("RTHIP_NO_BIG_LEAF")) {
+				auto diag = [](const Builder::Item& it) {
+					double dx = it.b.hi[0] - it.b.lo[0], dy = it.b.hi[1] - it.b.lo[1], dz = it.b.hi[2] - it.b.lo[2];
+					return std::sqrt(dx * dx + dy * dy + dz * dz);
+				};
+				std::vector<double> d(m);
+				for (size_t i = 0; i < m; i++) d[i] = diag(b.items[i]);
+				std::nth_element(d.begin(), d.begin() + (long)(m / 2), d.end());
+				const double limit = 64.0 * d[m / 2];
+				int ns = 0, nc = 0;
+				for (size_t i = 0; i < m; i++)
+					if (diag(b.items[i]) > limit) { big.push_back(b.items[i].id); (objs[b.items[i].id].kind == RTHIP_SPHERE ? ns : nc)++; }
+				if (big.empty() || ns > 7 || nc > 7) {
+					big.clear();  // none, or more than one leaf code can hold: leave the tree as it is
+				} else {
+					b.items.erase(std::remove_if(b.items.begin(), b.items.end(), [&](const Builder::Item& it) { return diag(it) > limit; }), b.items.end());
+					m = b.items.size();
+				}
+			}
+			big_ids_empty = big.empty();
+			if (!big.empty()) {
+				Builder::Sub bl = b.emit_leaf(big.data(), (int)big.size());  // node 0 is already reserved for the root
+				Builder::Sub rest = b.sah_build(0, m, 1);
+				b.write_node(root, bl, rest);
+				if (b.max_depth < 1) b.max_depth = 1;
+			} else if (m <= (size_t)b.max_leaf) {
+				l = m ? b.sah_leaf(0, m) : r;
+			} else {
+				// the root's two children are the two halves of the first split
+				out->nodes64.pop_back();
+				out->nodes32.pop_back();
+				Builder::Sub whole = b.sah_build(0, m, 0);
+				(void)whole;
+				root = 0;
+			}
+			if (big.empty() && m <= (size_t)b.max_leaf) { b.write_node(root, l, r); b.max_depth = 1; }
+		};
+		// Waves a CU keeps resident when every workgroup holds the f32 scene and its traversal stacks
+		// in LDS (160 KB; 7 workgroups of 256 or 3 of 512 threads at most by registers).  Going from 24
+		// to 16 resident waves costs 17 % on the default scene, far more than a coarser tree does.
+		auto resident_waves = [&]() {
+			auto up = [](size_t v) { return (v + 63) / 64 * 64; };
+			size_t scene = up(out->nodes32.size() * sizeof(Node<float>)) + up(out->prims32.size() * sizeof(Prim<float>)) + up(out->gates32.size() * sizeof(Gate<float>));
+			if (scene > 64 * 1024) return 0;
+			int best = 0;
+			for (int threads : {256, 512}) {
+				size_t per = (size_t)std::max(1, b.max_depth) * (size_t)threads * 4 + scene;
+				int blocks = std::min(28 / (threads / 64), (int)(160 * 1024 / per));
+				best = std::max(best, blocks * threads / 64);
+			}
+			return best;
+		};
+		size_t n_hittable = 0;
+		for (int64_t i = 0; i < n; i++) n_hittable += b.can_be_hit((int32_t)i) ? 1 : 0;
+		if (std::getenv("RTHIP_SAH_CPRIM") || n_hittable * sizeof(Prim<float>) > 64 * 1024) {
+			attempt(b.cost_prim);  // as asked, or a scene for global memory: the value tuned there
 		} else {
-			// the root's two children are the two halves of the first split
-			out->nodes64.pop_back();
-			out->nodes32.pop_back();
-			Builder::Sub whole = b.sah_build(0, m, 0);
-			(void)whole;
-			root = 0;
+			// The finer the tree, the fewer primitive tests per ray (up to a cost of about one
+			// node visit per test); take the finest one that keeps the CU full, else the fullest.
+			static const double ladder[] = {0.7, 0.5, 0.4, 0.3, 0.2};
+			double pick = ladder[0];
+			int pick_waves = -1;
+			for (double c : ladder) {
+				attempt(c);
+				int w = resident_waves();
+				if (w > pick_waves) { pick_waves = w; pick = c; }
+				if (w >= 24) break;
+			}
+			if (pick_waves == 0) pick = 0.4;  // no tree fits LDS: the value tuned for global memory
+			if (b.cost_prim != pick) attempt(pick);
 		}
-		if (big.empty() && m <= (size_t)b.max_leaf) { b.write_node(root, l, r); b.max_depth = 1; }
 	} else {
+		root = b.new_node();
 		if (b.ref_nodes[(size_t)ref_root].left < 0) {
 			l = b.shape_ref(ref_root, 0);
 			b.write_node(root, l, r);

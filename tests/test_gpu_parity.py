@@ -460,3 +460,18 @@ def test_axis_aligned_camera_rays(rt, oracle, monkeypatch):
     for a, b in zip(ref, got):
         assert np.array_equal(a, b)
     r.close()
+
+
+@pytest.mark.gpu
+def test_tree_fineness_follows_the_lds_budget(rt):
+    """Scenes that can keep 24 waves per CU resident (three 512-thread workgroups, each with its
+    own scene copy and traversal stacks in 160 KB of LDS) get the finest surface-area tree that
+    still does; a fixed fineness falls to 16 waves (-17 % and more) from about 550 objects on."""
+    cam = rt.Camera((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0, 128, 72)
+    for n, blocks in ((300, 3), (500, 3), (600, 3), (1000, 2)):
+        r = rt.Renderer(rt.create_synthetic_scene(n, seed=0x5EED0001), cam, max_depth=4, seed=1)
+        r.accumulate(1)
+        s = r.stats()
+        per_block = s["n_nodes"] * 64 + s["n_prims"] * 32 + s["tree_depth"] * 512 * 4
+        assert per_block <= 160 * 1024 // blocks, (n, s["n_nodes"], s["tree_depth"])
+        r.close()
