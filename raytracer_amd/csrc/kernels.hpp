@@ -360,8 +360,12 @@ __device__ __forceinline__ bool hit_box_fused(const float* b, V3<float> scale, V
 	float y0 = __builtin_fmaf(b[kBoxLoY], scale.y, offset.y), y1 = __builtin_fmaf(b[kBoxHiY], scale.y, offset.y);
 	float z0 = __builtin_fmaf(b[kBoxLoZ], scale.z, offset.z), z1 = __builtin_fmaf(b[kBoxHiZ], scale.z, offset.z);
 	float tnear = Fp<float>::fmax(Fp<float>::fmax(Fp<float>::fmin(x0, x1), Fp<float>::fmin(y0, y1)), Fp<float>::fmin(z0, z1));
-	float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(x0, x1), Fp<float>::fmax(y0, y1)),
-	                             Fp<float>::fmin(Fp<float>::fmax(z0, z1), best_t));
+	float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(x0, x1), Fp<float>::fmax(y0, y1)), Fp<float>::fmax(z0, z1));
+	// min(tfar, best_t) on the bit patterns: best_t is positive (or +inf) and tfar is never NaN
+	// (finite planes, finite scale and offset), so the signed-integer order is the float order,
+	// and unlike v_min_f32 the integer min needs no canonicalised operand (the compiler re-did
+	// v_max best_t, best_t in every iteration of the node loop).
+	tfar = __builtin_bit_cast(float, __builtin_bit_cast(int32_t, tfar) < __builtin_bit_cast(int32_t, best_t) ? __builtin_bit_cast(int32_t, tfar) : __builtin_bit_cast(int32_t, best_t));
 	*entry = tnear;
 	return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, eps);
 }
