@@ -456,8 +456,19 @@ struct Builder {
 				static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
 				n64.box[6 * c + lo_slot[k]] = ch[c]->b64.lo[k];
 				n64.box[6 * c + hi_slot[k]] = ch[c]->b64.hi[k];
-				n32.box[6 * c + lo_slot[k]] = round_down(ch[c]->b32.lo[k]);
-				n32.box[6 * c + hi_slot[k]] = round_up(ch[c]->b32.hi[k]);
+				// f32: centre (in the lo slot) and half extent (in the hi slot), see hit_box_centred.  The
+				// half extent is taken from the rounded centre and widened by 2^-20 for the rounding of
+				// tc -/+ th in the kernel; an empty box gets a negative one and is never hit.
+				const double lo = ch[c]->b32.lo[k], hi = ch[c]->b32.hi[k];
+				if (lo <= hi) {
+					const float centre = (float)(0.5 * lo + 0.5 * hi);
+					const double half = std::fmax(hi - (double)centre, (double)centre - lo);
+					n32.box[6 * c + lo_slot[k]] = centre;
+					n32.box[6 * c + hi_slot[k]] = round_up(half * (1.0 + 0x1p-20) + 1e-37);
+				} else {
+					n32.box[6 * c + lo_slot[k]] = 0.0f;
+					n32.box[6 * c + hi_slot[k]] = -1e30f;
+				}
 			}
 			n64.child[c] = ch[c]->code;
 			n32.child[c] = ch[c]->code;
@@ -821,11 +832,19 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	if (use_sah && out->nodes32.size() > 2048 && !std::getenv("RTHIP_NO_QNODES")) {
 		const Node<float>& n0 = out->nodes32[0];
 		const bool has_big = !big_ids_empty;
+		// planes of child c of an f32 node (stored as centre and half extent) on axis k; an empty box has lo > hi
+		auto plane_lo = [](const Node<float>& n, int c, int k) {
+			static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+			return n.box[6 * c + hi_slot[k]] < 0.0f ? (double)INFINITY : (double)n.box[6 * c + lo_slot[k]] - (double)n.box[6 * c + hi_slot[k]];
+		};
+		auto plane_hi = [](const Node<float>& n, int c, int k) {
+			static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+			return n.box[6 * c + hi_slot[k]] < 0.0f ? -(double)INFINITY : (double)n.box[6 * c + lo_slot[k]] + (double)n.box[6 * c + hi_slot[k]];
+		};
 		double lo[3], hi[3];
 		for (int k = 0; k < 3; k++) {
-			static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
-			lo[k] = has_big ? n0.box[6 + lo_slot[k]] : std::fmin(n0.box[lo_slot[k]], n0.box[6 + lo_slot[k]]);
-			hi[k] = has_big ? n0.box[6 + hi_slot[k]] : std::fmax(n0.box[hi_slot[k]], n0.box[6 + hi_slot[k]]);
+			lo[k] = has_big ? plane_lo(n0, 1, k) : std::fmin(plane_lo(n0, 0, k), plane_lo(n0, 1, k));
+			hi[k] = has_big ? plane_hi(n0, 1, k) : std::fmax(plane_hi(n0, 0, k), plane_hi(n0, 1, k));
 		}
 		QFrame& f = out->qframe;
 		for (int k = 0; k < 3; k++) {
@@ -843,7 +862,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 			for (int c = 0; c < 2; c++) {
 				for (int k = 0; k < 3; k++) {
 					static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
-					double l = n.box[6 * c + lo_slot[k]], h = n.box[6 * c + hi_slot[k]];
+					double l = plane_lo(n, c, k), h = plane_hi(n, c, k);
 					if (!(l <= h)) { q.q[6 * c + lo_slot[k]] = kQMax; q.q[6 * c + hi_slot[k]] = -kQMax; continue; }  // empty box: never hit
 					double ql = std::floor((l - (double)f.centre[k]) / (double)f.step[k]) - 1.0;
 					double qh = std::ceil((h - (double)f.centre[k]) / (double)f.step[k]) + 1.0;

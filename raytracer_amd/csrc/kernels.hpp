@@ -37,9 +37,6 @@
 
 namespace rthip {
 
-#ifndef RT_FUSED_BOX
-#define RT_FUSED_BOX 1
-#endif
 #ifndef RT_QWAVES
 #define RT_QWAVES 7   // the global-memory variant is latency bound: one more wave per SIMD (72 VGPRs)
 #endif
@@ -237,7 +234,7 @@ RT_FN V3<Real> sky(V3<Real> u, int sky_mode) {  // u = the normalised direction
 // ---------------------------------------------------------------------------------------
 template <typename Real> struct TravRay {
 	V3<Real> o, d, inv;  // inv = 1 / d
-	V3<Real> noi;        // -(o * inv): the f32 box test is one fma per plane, plane * inv + noi
+	V3<Real> noi;        // -(o * inv): the f32 box test works on coordinate * inv + noi, one fma
 	Real eps;            // absolute slack that covers the rounding of that fma form
 	Real rcp_a;          // 1 / d.d (f32 sphere test)
 	V3<Real> qscale;     // quantised nodes only: step / d (noi and eps are then relative to the grid centre)
@@ -248,7 +245,7 @@ RT_FN TravRay<Real> prepare(RayT<Real> r, const QFrame* frame = nullptr) {
 	TravRay<Real> t;
 	t.o = r.o; t.d = r.d;
 	t.inv = mk<Real>(Fp<Real>::rcp(r.d.x), Fp<Real>::rcp(r.d.y), Fp<Real>::rcp(r.d.z));
-	if constexpr (std::is_same<Real, float>::value && RT_FUSED_BOX) {
+	if constexpr (std::is_same<Real, float>::value) {
 		// A zero (or flushed) direction component gives inv = inf and plane * inf - o * inf = NaN for
 		// every plane; a huge finite stand-in keeps the sign of (plane - o), which is all that axis
 		// contributes for such a ray.
@@ -369,26 +366,35 @@ __device__ __forceinline__ bool hit_box_fused(const float* b, V3<float> scale, V
 	*entry = tnear;
 	return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, eps);
 }
+// The f32 box of a full node is stored as centre and half extent: the distances to the two planes
+// of an axis are tc -/+ th with tc = centre * scale + offset and th = half * |scale| (the abs is
+// a source modifier), i.e. three FMAs per axis, and the near one is known without a min/max
+// pair.  On this part v_fma/v_mul/v_add issue in 2-3 cycles per wave and v_min/v_max/v_cndmask
+// in 4 (tools/microbench/oprate.hip), so this form is a third cheaper than two FMAs plus min and
+// max per axis.  The host inflates the half extent by 2^-20 for the rounding of tc -/+ th.
+__device__ __forceinline__ bool hit_box_centred(const float* b, V3<float> scale, V3<float> offset, float eps, float best_t, float* entry) {
+	const float cx = __builtin_fmaf(b[kBoxLoX], scale.x, offset.x), ax = __builtin_fabsf(scale.x);
+	const float cy = __builtin_fmaf(b[kBoxLoY], scale.y, offset.y), ay = __builtin_fabsf(scale.y);
+	const float cz = __builtin_fmaf(b[kBoxLoZ], scale.z, offset.z), az = __builtin_fabsf(scale.z);
+	const float tnear = Fp<float>::fmax(Fp<float>::fmax(__builtin_fmaf(-b[kBoxHiX], ax, cx), __builtin_fmaf(-b[kBoxHiY], ay, cy)), __builtin_fmaf(-b[kBoxHiZ], az, cz));
+	float tfar = Fp<float>::fmin(Fp<float>::fmin(__builtin_fmaf(b[kBoxHiX], ax, cx), __builtin_fmaf(b[kBoxHiY], ay, cy)), __builtin_fmaf(b[kBoxHiZ], az, cz));
+	tfar = __builtin_bit_cast(float, __builtin_bit_cast(int32_t, tfar) < __builtin_bit_cast(int32_t, best_t) ? __builtin_bit_cast(int32_t, tfar) : __builtin_bit_cast(int32_t, best_t));  // see hit_box_fused
+	*entry = tnear;
+	return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, eps);
+}
 RT_FN bool hit_box(const Real* b, const TravRay<Real>& r, Real best_t, Real* entry) {
-	if constexpr (std::is_same<Real, float>::value && RT_FUSED_BOX) {
-		return hit_box_fused(b, r.inv, r.noi, r.eps, best_t, entry);
+	if constexpr (std::is_same<Real, float>::value) {
+		return hit_box_centred(b, r.inv, r.noi, r.eps, best_t, entry);
 	} else {
 		Real tx0 = (b[kBoxLoX] - r.o.x) * r.inv.x, tx1 = (b[kBoxHiX] - r.o.x) * r.inv.x;
 		Real ty0 = (b[kBoxLoY] - r.o.y) * r.inv.y, ty1 = (b[kBoxHiY] - r.o.y) * r.inv.y;
 		Real tz0 = (b[kBoxLoZ] - r.o.z) * r.inv.z, tz1 = (b[kBoxHiZ] - r.o.z) * r.inv.z;
 		Real tnear = Fp<Real>::fmax(Fp<Real>::fmax(Fp<Real>::fmin(tx0, tx1), Fp<Real>::fmin(ty0, ty1)), Fp<Real>::fmin(tz0, tz1));
-		if constexpr (std::is_same<Real, float>::value) {  // separately rounded form: relative error only, no slack term
-			float tfar = Fp<float>::fmin(Fp<float>::fmin(Fp<float>::fmax(tx0, tx1), Fp<float>::fmax(ty0, ty1)),
-			                             Fp<float>::fmin(Fp<float>::fmax(tz0, tz1), best_t));
-			*entry = tnear;
-			return Fp<float>::fmax(tnear, 0.0009f) <= tfar * (1.0f + 0x1p-18f);
-		} else {
-			Real tfar = Fp<Real>::fmin(Fp<Real>::fmin(Fp<Real>::fmax(tx0, tx1), Fp<Real>::fmax(ty0, ty1)), Fp<Real>::fmax(tz0, tz1));
-			*entry = tnear;
-			const Real pad = Real(1.0 + 0x1p-30);
-			tfar = tfar * pad;
-			return tnear <= tfar && tfar > Real(0.001) && tnear <= best_t * pad;
-		}
+		Real tfar = Fp<Real>::fmin(Fp<Real>::fmin(Fp<Real>::fmax(tx0, tx1), Fp<Real>::fmax(ty0, ty1)), Fp<Real>::fmax(tz0, tz1));
+		*entry = tnear;
+		const Real pad = Real(1.0 + 0x1p-30);
+		tfar = tfar * pad;
+		return tnear <= tfar && tfar > Real(0.001) && tnear <= best_t * pad;
 	}
 }
 

@@ -32,7 +32,9 @@ constexpr int kBoxLoX = 0, kBoxLoY = 1, kBoxLoZ = 2, kBoxHiX = 3, kBoxHiY = 4, k
 
 template <typename Real>
 struct alignas(sizeof(Real) * 16) Node {
-	Real box[12];      // per child (left, then right) six planes in the order of kBox* above
+	Real box[12];      // per child (left, then right): f64 six planes in the order of kBox* above;
+	                   // f32 centre.xyz in the lo slots and half extent.xyz (widened by 2^-20,
+	                   // negative for an empty box) in the hi slots
 	int32_t child[2];  // left, right
 };
 static_assert(sizeof(Node<float>) == 64, "f32 node is one 64-byte line");
