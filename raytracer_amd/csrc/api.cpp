@@ -38,6 +38,7 @@ struct rthip_ctx {
 	bool has_scene = false, has_camera = false;
 	SceneBlob blob32, blob64;
 	int tree_depth = 0, n_nodes = 0, n_leaves = 0, n_prims = 0;
+	int32_t big_leaf = 0, start = 0;  // leaf of oversized primitives tested at ray start, and the tree's entry after it
 
 	CameraFields cam{};
 	int tiles_x = 0, tiles_y = 0;
@@ -209,6 +210,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.scene = blob.dev; a.prims_off = blob.prims_off; a.mats_off = blob.mats_off; a.gates_off = blob.gates_off; a.scene_bytes = blob.bytes;
 	a.lds_bytes = blob.lds_bytes;
 	a.qnodes_off = blob.qnodes_off; a.qframe = blob.qframe;
+	a.big_leaf = c->big_leaf; a.start = c->start;
 	a.stack_entries = c->tree_depth;
 	fill_camera<Real>(c->cam, &a.cam);
 	a.width = c->cam.width; a.height = c->cam.height; a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y;
@@ -416,6 +418,7 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 	if (rc != RTHIP_OK) return rc;
 	rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
 	if (rc != RTHIP_OK) return rc;
+	c->big_leaf = flat.big_leaf; c->start = flat.start;
 	c->tree_depth = flat.depth; c->n_nodes = (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)flat.prims32.size();
 	c->stats.n_nodes = c->n_nodes; c->stats.n_leaves = c->n_leaves; c->stats.n_prims = c->n_prims; c->stats.tree_depth = c->tree_depth;
 	c->has_scene = true;

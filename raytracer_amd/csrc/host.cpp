@@ -825,6 +825,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	}
 	lap("device tree");
 	out->depth = std::max(1, b.max_depth);
+	if (use_sah && !big_ids_empty) { out->big_leaf = out->nodes32[0].child[0]; out->start = out->nodes32[0].child[1]; }
 	if (out->depth > kStackMax) { *err = "tree deeper than the traversal stack"; return false; }
 	// 3. large scenes: the quantised copy of the f32 nodes (see QNode).  The grid spans the boxes
 	// of the surface-area tree; the leaf of oversized primitives stays outside it (node 0, which

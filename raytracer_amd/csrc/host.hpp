@@ -36,6 +36,8 @@ struct FlatScene {
 	std::vector<Gate<double>> gates64;
 	std::vector<QNode> qnodes;  // f32, large scenes only (empty otherwise): quantised copy of nodes32
 	QFrame qframe{};
+	int32_t big_leaf = 0;  // leaf of oversized primitives that every ray tests before the tree (0 = none) ...
+	int32_t start = 0;     // ... and where traversal starts then: node 0's right child (an inner node or a leaf code)
 	int depth = 0;      // device tree: levels of inner nodes on the longest root-to-leaf path
 	int ref_depth = 0;  // the same for the reference's tree
 	int n_leaves = 0;

@@ -53,7 +53,9 @@ struct RenderArgs {
 	uint32_t prims_off, mats_off, gates_off, scene_bytes;
 	uint32_t lds_bytes;     // leading part of the blob that LDS-resident launches copy (all but the materials)
 	uint32_t qnodes_off;    // quantised nodes (f32 blobs of large scenes), 0 = none
-	QFrame qframe;          // their grid, where traversal starts, and the leaf of oversized primitives
+	QFrame qframe;          // their grid
+	int32_t big_leaf;       // leaf code of the oversized primitives every ray tests first, 0 = none
+	int32_t start;          // where traversal starts after them: an inner node or a leaf code (0 without big_leaf)
 	int32_t stack_entries;  // tree depth
 	CameraT<Real> cam;
 	int32_t width, height, tiles_x, tiles_y;
@@ -521,10 +523,10 @@ __device__ __forceinline__ void trav_inner_q(Trav<float>& tv, const TravRay<floa
 }
 // Tests the primitives of the leaf in tv.cur (the caller guarantees a leaf code) as one run of
 // spheres and one run of cubes, then pops.
-template <typename Real, int kThreads, bool kCount>
-__device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, const Gate<Real>* gates, int* stack, Tally& tally, Regions& rg) {
+template <typename Real, bool kCount>
+__device__ __forceinline__ void leaf_tests(Trav<Real>& tv, const TravRay<Real>& r, int32_t leaf, const Prim<Real>* prims, const Gate<Real>* gates, Tally& tally, Regions& rg) {
 	region_tick<kCount>(rg, kRegLeaf);
-	const uint32_t code = ~(uint32_t)tv.cur;
+	const uint32_t code = ~(uint32_t)leaf;
 	const int32_t first = (int32_t)(code >> 6), ns = (int32_t)((code >> 3) & 7u), nc = (int32_t)(code & 7u);
 	auto better = [&](Real t, int32_t i) {
 		return t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && prims[i].rank > prims[tv.best_prim].rank));
@@ -549,6 +551,10 @@ __device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r
 		if (kCount) tally.cube++;
 		if (hit_cube<Real>(prims[i], r, &t) && better(t, i)) { tv.best_t = t; tv.best_prim = i; }
 	}
+}
+template <typename Real, int kThreads, bool kCount>
+__device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, const Gate<Real>* gates, int* stack, Tally& tally, Regions& rg) {
+	leaf_tests<Real, kCount>(tv, r, tv.cur, prims, gates, tally, rg);
 	trav_pop<Real, kThreads>(tv, stack);
 }
 
@@ -841,16 +847,14 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 		// rays made above by shading (next bounce) and by regeneration (camera rays) are set up together
 		if (state == kFresh) {
 			trav_begin<Real>(tv);
-			if constexpr (kQ) {
-				ray = prepare<Real>(RayT<Real>{ray.o, ray.d}, &A.qframe);
-				tv.cur = A.qframe.start;
-				if (A.qframe.big_leaf != 0) {  // the oversized primitives first, the tree after them
-					stack[0] = A.qframe.start;
-					tv.sp = 1;
-					tv.cur = A.qframe.big_leaf;
-				}
-			} else {
-				ray = prepare<Real>(RayT<Real>{ray.o, ray.d});
+			if constexpr (kQ) ray = prepare<Real>(RayT<Real>{ray.o, ray.d}, &A.qframe);
+			else ray = prepare<Real>(RayT<Real>{ray.o, ray.d});
+			// The oversized primitives (ground slab, sun) first: every ray tests them, here the lanes
+			// that start a ray do so together instead of one by one in the leaf loops, and the tree
+			// below is walked with their hit distance already known.
+			if (A.big_leaf != 0) {
+				leaf_tests<Real, kCount>(tv, ray, A.big_leaf, prims, gates, tally, rg);
+				tv.cur = A.start;
 			}
 			state = kTraverse;
 		}

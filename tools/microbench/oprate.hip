@@ -29,10 +29,26 @@ constexpr int kIters = 2048;
 #define I_RCP(r) "v_rcp_f32 " #r ", " #r
 #define I_SQRT(r) "v_sqrt_f32 " #r ", " #r
 #define I_CVT(r) "v_cvt_f32_i32 " #r ", " #r
-#define I_PKFMA(r) "v_pk_mul_f32 %0, %0, %1"
+#define I_MULLO(r) "v_mul_lo_u32 " #r ", " #r ", %8"
+#define I_XOR(r) "v_xor_b32 " #r ", " #r ", %8"
+#define I_LSHR(r) "v_lshrrev_b32 " #r ", 3, " #r
+#define I_LSHRV(r) "v_lshrrev_b32 " #r ", %8, " #r
+#define I_RSQ(r) "v_rsq_f32 " #r ", " #r
+#define I_CVTU(r) "v_cvt_f32_u32 " #r ", " #r
+#define I_FMAC(r) "v_fmac_f32 " #r ", %8, %9"
+#define I_FMAS(r) "v_fma_f32 " #r ", " #r ", s2, %9"
+#define I_FMAABS(r) "v_fma_f32 " #r ", -" #r ", |%8|, %9"
+#define I_CNDVCC(r) "v_cndmask_b32 " #r ", " #r ", %8, vcc"
+#define I_MAD24(r) "v_mad_u32_u24 " #r ", " #r ", %8, %9"
+#define I_BFE(r) "v_bfe_u32 " #r ", " #r ", 3, 5"
+#define I_MULK(r) "v_mul_f32 " #r ", 0x3f800020, " #r
+#define I_MED3(r) "v_med3_f32 " #r ", " #r ", %8, %9"
+#define I_SUB(r) "v_sub_f32 " #r ", " #r ", %8"
 KERNEL(k_fma, I_FMA) KERNEL(k_mul, I_MUL) KERNEL(k_add, I_ADD) KERNEL(k_min, I_MIN) KERNEL(k_max3, I_MAX3) KERNEL(k_mov, I_MOV)
 KERNEL(k_cnd, I_CND) KERNEL(k_iadd, I_IADD) KERNEL(k_and, I_AND) KERNEL(k_lshladd, I_LSHLADD) KERNEL(k_cmp, I_CMP) KERNEL(k_mini, I_MINI)
 KERNEL(k_rcp, I_RCP) KERNEL(k_sqrt, I_SQRT) KERNEL(k_cvt, I_CVT)
+KERNEL(k_mullo, I_MULLO) KERNEL(k_xor, I_XOR) KERNEL(k_lshr, I_LSHR) KERNEL(k_lshrv, I_LSHRV) KERNEL(k_rsq, I_RSQ) KERNEL(k_cvtu, I_CVTU) KERNEL(k_fmac, I_FMAC)
+KERNEL(k_fmas, I_FMAS) KERNEL(k_fmaabs, I_FMAABS) KERNEL(k_cndvcc, I_CNDVCC) KERNEL(k_mad24, I_MAD24) KERNEL(k_bfe, I_BFE) KERNEL(k_mulk, I_MULK) KERNEL(k_med3, I_MED3) KERNEL(k_sub, I_SUB)
 int main() {
 	hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
 	const int cus = p.multiProcessorCount, grid = cus * 8 * 4;
@@ -42,7 +58,9 @@ int main() {
 	struct { const char* name; void (*k)(float*, float, float); } ks[] = {
 		{"v_fma_f32", k_fma}, {"v_mul_f32", k_mul}, {"v_add_f32", k_add}, {"v_min_f32", k_min}, {"v_max3_f32", k_max3}, {"v_mov_b32", k_mov},
 		{"v_cndmask_b32", k_cnd}, {"v_add_u32", k_iadd}, {"v_and_b32", k_and}, {"v_lshl_add_u32", k_lshladd}, {"v_cmp_lt_f32", k_cmp}, {"v_min_i32", k_mini},
-		{"v_rcp_f32", k_rcp}, {"v_sqrt_f32", k_sqrt}, {"v_cvt_f32_i32", k_cvt}};
+		{"v_rcp_f32", k_rcp}, {"v_sqrt_f32", k_sqrt}, {"v_cvt_f32_i32", k_cvt},
+		{"v_mul_lo_u32", k_mullo}, {"v_xor_b32", k_xor}, {"v_lshrrev_b32 imm", k_lshr}, {"v_lshrrev_b32 v", k_lshrv}, {"v_rsq_f32", k_rsq}, {"v_cvt_f32_u32", k_cvtu}, {"v_fmac_f32", k_fmac},
+		{"v_fma_f32 sgpr", k_fmas}, {"v_fma_f32 -a,|b|", k_fmaabs}, {"v_cndmask vcc", k_cndvcc}, {"v_mad_u32_u24", k_mad24}, {"v_bfe_u32", k_bfe}, {"v_mul_f32 literal", k_mulk}, {"v_med3_f32", k_med3}, {"v_sub_f32", k_sub}};
 	for (auto& c : ks) {
 		hipLaunchKernelGGL(c.k, dim3(grid), dim3(256), 0, 0, out, 1.0001f, 0.5f);
 		(void)hipDeviceSynchronize();
