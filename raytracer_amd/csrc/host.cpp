@@ -864,12 +864,13 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 				for (int k = 0; k < 3; k++) {
 					static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
 					double l = plane_lo(n, c, k), h = plane_hi(n, c, k);
-					if (!(l <= h)) { q.q[6 * c + lo_slot[k]] = kQMax; q.q[6 * c + hi_slot[k]] = -kQMax; continue; }  // empty box: never hit
+					if (!(l <= h)) { q.q[6 * c + lo_slot[k]] = kQMax; q.q[6 * c + hi_slot[k]] = 0; continue; }  // empty box: a far corner point (it leads to an empty leaf anyway)
 					double ql = std::floor((l - (double)f.centre[k]) / (double)f.step[k]) - 1.0;
 					double qh = std::ceil((h - (double)f.centre[k]) / (double)f.step[k]) + 1.0;
 					if (ql < -kQMax || qh > kQMax) ok = false;
-					q.q[6 * c + lo_slot[k]] = (int16_t)std::fmax(ql, -kQMax);
-					q.q[6 * c + hi_slot[k]] = (int16_t)std::fmin(qh, kQMax);
+					ql = std::fmax(ql, -kQMax); qh = std::fmin(qh, kQMax);
+					q.q[6 * c + lo_slot[k]] = (int16_t)ql;
+					q.q[6 * c + hi_slot[k]] = (int16_t)(uint16_t)(qh - ql);  // width, unsigned
 				}
 				q.child[c] = n.child[c];
 			}

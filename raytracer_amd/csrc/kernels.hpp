@@ -240,6 +240,7 @@ template <typename Real> struct TravRay {
 	Real eps;            // absolute slack that covers the rounding of that fma form
 	Real rcp_a;          // 1 / d.d (f32 sphere test)
 	V3<Real> qscale;     // quantised nodes only: step / d (noi and eps are then relative to the grid centre)
+	V3<Real> qneg;       // min(qscale, 0) per axis
 };
 // `frame` (f32 traversal over quantised nodes) moves the box-test operands into grid units; the
 // primitive tests keep using o, d, inv.
@@ -265,6 +266,7 @@ RT_FN TravRay<Real> prepare(RayT<Real> r, const QFrame* frame = nullptr) {
 			reach = Real(1);
 		}
 	}
+	t.qneg = mk<Real>(Fp<Real>::fmin(t.qscale.x, Real(0)), Fp<Real>::fmin(t.qscale.y, Real(0)), Fp<Real>::fmin(t.qscale.z, Real(0)));
 	t.noi = -(box_o * t.inv);
 	// plane*inv - o*inv is exact to an ulp of |o*inv| (not of the result): widen by 4 ulps of the
 	// largest term.  Only axes the ray actually advances along count (|d_a| >= 2^-12 max|d|): on a
@@ -384,6 +386,20 @@ __device__ __forceinline__ bool hit_box_centred(const float* b, V3<float> scale,
 	*entry = tnear;
 	return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, eps);
 }
+// Quantised child box: low plane and width per axis in grid steps.  With tlo the distance to the
+// low plane, the near one is tlo + width * min(scale, 0) and the far one that + width * |scale|:
+// three FMAs per axis, no min/max pair (see hit_box_centred for why that is cheaper here).
+__device__ __forceinline__ bool hit_box_q(const float* b, V3<float> scale, V3<float> sneg, V3<float> offset, float eps, float best_t, float* entry) {
+	const float nx = __builtin_fmaf(b[kBoxHiX], sneg.x, __builtin_fmaf(b[kBoxLoX], scale.x, offset.x));
+	const float ny = __builtin_fmaf(b[kBoxHiY], sneg.y, __builtin_fmaf(b[kBoxLoY], scale.y, offset.y));
+	const float nz = __builtin_fmaf(b[kBoxHiZ], sneg.z, __builtin_fmaf(b[kBoxLoZ], scale.z, offset.z));
+	const float tnear = Fp<float>::fmax(Fp<float>::fmax(nx, ny), nz);
+	float tfar = Fp<float>::fmin(Fp<float>::fmin(__builtin_fmaf(b[kBoxHiX], __builtin_fabsf(scale.x), nx), __builtin_fmaf(b[kBoxHiY], __builtin_fabsf(scale.y), ny)),
+	                             __builtin_fmaf(b[kBoxHiZ], __builtin_fabsf(scale.z), nz));
+	tfar = __builtin_bit_cast(float, __builtin_bit_cast(int32_t, tfar) < __builtin_bit_cast(int32_t, best_t) ? __builtin_bit_cast(int32_t, tfar) : __builtin_bit_cast(int32_t, best_t));  // see hit_box_fused
+	*entry = tnear;
+	return Fp<float>::fmax(tnear, 0.0009f) <= __builtin_fmaf(tfar, 1.0f + 0x1p-18f, eps);
+}
 RT_FN bool hit_box(const Real* b, const TravRay<Real>& r, Real best_t, Real* entry) {
 	if constexpr (std::is_same<Real, float>::value) {
 		return hit_box_centred(b, r.inv, r.noi, r.eps, best_t, entry);
@@ -498,13 +514,16 @@ __device__ __forceinline__ void trav_inner_q(Trav<float>& tv, const TravRay<floa
 		region_tick<kCount>(rg, kRegInner);
 		const uint4* p = reinterpret_cast<const uint4*>(nodes + tv.cur);
 		const uint4 a = p[0], b = p[1];
-		auto lo16 = [](uint32_t w) { return (float)(int16_t)(uint16_t)(w & 0xffffu); };
-		auto hi16 = [](uint32_t w) { return (float)((int32_t)w >> 16); };
-		const float pl[12] = {lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z),
-		                      lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y)};
+		// per child: three signed low planes, then three unsigned widths
+		auto s_lo = [](uint32_t w) { return (float)(int16_t)(uint16_t)(w & 0xffffu); };
+		auto s_hi = [](uint32_t w) { return (float)((int32_t)w >> 16); };
+		auto u_lo = [](uint32_t w) { return (float)(w & 0xffffu); };
+		auto u_hi = [](uint32_t w) { return (float)(w >> 16); };
+		const float pl[12] = {s_lo(a.x), s_hi(a.x), s_lo(a.y), u_hi(a.y), u_lo(a.z), u_hi(a.z),
+		                      s_lo(a.w), s_hi(a.w), s_lo(b.x), u_hi(b.x), u_lo(b.y), u_hi(b.y)};
 		float el, er;
-		bool hl = hit_box_fused(pl, r.qscale, r.noi, r.eps, tv.best_t, &el);
-		bool hr = hit_box_fused(pl + 6, r.qscale, r.noi, r.eps, tv.best_t, &er);
+		bool hl = hit_box_q(pl, r.qscale, r.qneg, r.noi, r.eps, tv.best_t, &el);
+		bool hr = hit_box_q(pl + 6, r.qscale, r.qneg, r.noi, r.eps, tv.best_t, &er);
 		int32_t cl = (int32_t)b.z, cr = (int32_t)b.w;
 		if (kCount) tally.box += 2;
 		if (hl && hr) {
@@ -762,7 +781,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	tv.cur = kDone; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
 	rng.state = 0; rng.inc = 1;
 	T = L = mk<Real>(0, 0, 0);
-	ray.o = ray.d = ray.inv = ray.noi = ray.qscale = T; ray.eps = ray.rcp_a = 0;
+	ray.o = ray.d = ray.inv = ray.noi = ray.qscale = ray.qneg = T; ray.eps = ray.rcp_a = 0;
 
 	// wave state (uniform)
 	// Work items are cut into kQueues contiguous ranges (bands of the image), each with its own

@@ -44,7 +44,7 @@ static_assert(sizeof(Node<float>) == 64, "f32 node is one 64-byte line");
 // (QFrame: plane = centre + q * step per axis), rounded outward by at least one step, so every
 // box contains the box it stands for and the closest hit is unchanged.  Two 16-byte loads.
 struct alignas(32) QNode {
-	int16_t q[12];     // same plane order as Node::box
+	int16_t q[12];     // per child: low planes x, y, z (signed steps), then widths x, y, z (unsigned steps)
 	int32_t child[2];
 };
 static_assert(sizeof(QNode) == 32, "quantised node is 32 bytes");
