@@ -166,6 +166,15 @@ int32_t rthip_get_stats(rthip_ctx* ctx, rthip_stats* out);
 int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* ids, int32_t* leaf_sizes, int64_t* n_leaves,
                              int32_t* depth);
 
+/* Host-only self-check (no counterpart in the reference: its tree is never wrong by construction,
+ * this one is conservative by rounding rules that deserve a test).  Builds the device tree as
+ * rthip_scene_upload would and verifies that every f32 child box, and every quantised one,
+ * contains the f32 bounds of all primitives below it, that every object that can be hit sits
+ * in exactly one leaf, and that the depth is as reported.  violations = 0 and RTHIP_OK when
+ * sound; otherwise RTHIP_ERR_STATE and rthip_last_error(NULL) describes the first violation.
+ * Any output pointer may be NULL. */
+int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* violations, int32_t* n_nodes, int32_t* depth);
+
 /* Seeded scene factories (no GPU needed).  Same distributions as the reference's factories,
  * which draw from an OS-seeded generator and are therefore not reproducible themselves:
  *   "default"   Scene::create_sample_scene          src/scene.rs:122-205

@@ -687,6 +687,21 @@ int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* id
 	return RTHIP_OK;
 }
 
+int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* violations, int32_t* n_nodes, int32_t* depth) {
+	if (n < 0 || (n > 0 && !objects)) return fail(nullptr, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
+	if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
+	FlatScene flat;
+	std::string err;
+	if (!build_flat_scene(objects, n, &flat, &err)) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+	std::string first;
+	const int64_t bad = validate_flat_scene(flat, n, &first);
+	if (violations) *violations = bad;
+	if (n_nodes) *n_nodes = (int32_t)flat.nodes32.size();
+	if (depth) *depth = flat.depth;
+	if (bad) return fail(nullptr, RTHIP_ERR_STATE, first);
+	return RTHIP_OK;
+}
+
 int32_t rthip_scene_generate(const char* name, uint32_t seed, rthip_object* out, int64_t capacity, int64_t* n) {
 	if (!name || !n) return fail(nullptr, RTHIP_ERR_INVALID, "name or n is NULL");
 	std::vector<rthip_object> objs;

@@ -4,6 +4,7 @@
 #include "host.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -878,6 +879,77 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		if (!ok) out->qnodes.clear();  // cannot happen with the headroom above; the full nodes are always valid
 	}
 	return true;
+}
+
+int64_t validate_flat_scene(const FlatScene& s, int64_t n_objects, std::string* first) {
+	int64_t bad = 0;
+	auto report = [&](const std::string& what) { if (bad++ == 0 && first) *first = what; };
+	struct B { double lo[3], hi[3]; };
+	auto prim_bounds = [&](const Prim<float>& p) {
+		B b;
+		const bool sphere = ((p.id >> kKindShift) & 1) == RTHIP_SPHERE;
+		for (int k = 0; k < 3; k++) {
+			static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+			if (sphere) { b.lo[k] = (double)p.v[k] - std::fabs((double)p.v[3]); b.hi[k] = (double)p.v[k] + std::fabs((double)p.v[3]); }
+			else { b.lo[k] = p.v[lo_slot[k]]; b.hi[k] = p.v[hi_slot[k]]; }
+		}
+		return b;
+	};
+	std::vector<int> seen((size_t)n_objects, 0);
+	std::vector<char> prim_used(s.prims32.size(), 0);
+	const bool quantised = !s.qnodes.empty();
+	int deepest = 0;
+	// bounds of the subtree behind a child code; checks every box on the way up
+	std::function<B(int32_t, int)> walk = [&](int32_t code, int depth) -> B {
+		B b;
+		for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
+		if (code < 0) {
+			const uint32_t c = ~(uint32_t)code;
+			const int32_t first_prim = (int32_t)(c >> 6), cnt = (int32_t)((c >> 3) & 7u) + (int32_t)(c & 7u);
+			for (int32_t i = first_prim; i < first_prim + cnt; i++) {
+				if (i < 0 || (size_t)i >= s.prims32.size()) { report("leaf points outside the primitive array"); continue; }
+				if (prim_used[(size_t)i]++) report("primitive " + std::to_string(i) + " is in two leaves");
+				const int32_t id = s.prims32[(size_t)i].id & ((1 << kMatShift) - 1);
+				if (id < 0 || id >= n_objects) report("primitive with an object id out of range"); else seen[(size_t)id]++;
+				B pb = prim_bounds(s.prims32[(size_t)i]);
+				for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(b.lo[k], pb.lo[k]); b.hi[k] = std::fmax(b.hi[k], pb.hi[k]); }
+			}
+			return b;
+		}
+		if ((size_t)code >= s.nodes32.size()) { report("child index outside the node array"); return b; }
+		deepest = std::max(deepest, depth + 1);
+		const Node<float>& n = s.nodes32[(size_t)code];
+		for (int c = 0; c < 2; c++) {
+			B cb = walk(n.child[c], depth + 1);
+			for (int k = 0; k < 3; k++) {
+				static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+				if (!(cb.lo[k] <= cb.hi[k])) continue;  // nothing below: any box will do
+				const double centre = n.box[6 * c + lo_slot[k]], half = n.box[6 * c + hi_slot[k]];
+				if (!(centre - half <= cb.lo[k] && centre + half >= cb.hi[k]))
+					report("node " + std::to_string(code) + " child " + std::to_string(c) + " axis " + std::to_string(k) + ": f32 box does not contain its primitives");
+				if (quantised && !(code == 0 && s.big_leaf != 0)) {
+					const QNode& q = s.qnodes[(size_t)code];
+					const double lo = (double)s.qframe.centre[k] + (double)q.q[6 * c + lo_slot[k]] * (double)s.qframe.step[k];
+					const double hi = lo + (double)(uint16_t)q.q[6 * c + hi_slot[k]] * (double)s.qframe.step[k];
+					if (!(lo <= cb.lo[k] && hi >= cb.hi[k]))
+						report("node " + std::to_string(code) + " child " + std::to_string(c) + " axis " + std::to_string(k) + ": quantised box does not contain its primitives");
+					if (q.child[c] != n.child[c]) report("quantised node " + std::to_string(code) + " has other children than the full node");
+				}
+				b.lo[k] = std::fmin(b.lo[k], cb.lo[k]); b.hi[k] = std::fmax(b.hi[k], cb.hi[k]);
+			}
+		}
+		return b;
+	};
+	if (s.nodes32.empty()) { report("no nodes"); return bad; }
+	walk(0, 0);
+	if (deepest > s.depth) report("tree deeper (" + std::to_string(deepest) + ") than reported (" + std::to_string(s.depth) + ")");
+	for (size_t i = 0; i < prim_used.size(); i++) if (!prim_used[i]) report("primitive " + std::to_string(i) + " is in no leaf");
+	for (int64_t i = 0; i < n_objects; i++) if (seen[(size_t)i] > 1) report("object " + std::to_string(i) + " appears more than once");
+	if (s.big_leaf != 0 && (s.nodes32[0].child[0] != s.big_leaf || s.nodes32[0].child[1] != s.start)) report("big_leaf/start do not match node 0");
+	if (s.nodes32.size() != s.nodes64.size() || s.prims32.size() != s.prims64.size()) report("f32 and f64 arrays differ in size");
+	for (size_t i = 0; i < s.nodes32.size() && i < s.nodes64.size(); i++)
+		if (s.nodes32[i].child[0] != s.nodes64[i].child[0] || s.nodes32[i].child[1] != s.nodes64[i].child[1]) { report("f32 and f64 trees differ in shape"); break; }
+	return bad;
 }
 
 }  // namespace rthip

@@ -46,5 +46,10 @@ struct FlatScene {
 };
 // Returns false (with a message) for an empty scene or non-finite input.
 bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err);
+// Checks the invariant every culling decision rests on: each f32 child box (centre and half
+// extent), and each quantised one, contains the f32 bounds of every primitive below it; every
+// primitive that can be hit is in exactly one leaf; the tree is no deeper than reported.
+// Returns the number of violations (0 = sound) and describes the first one.
+int64_t validate_flat_scene(const FlatScene& s, int64_t n_objects, std::string* first);
 
 }  // namespace rthip

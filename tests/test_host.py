@@ -158,3 +158,26 @@ def test_accum_word_packing_roundtrip():
     words = pack_accum_words(img, 37, 23)
     assert words.size == 5 * 3 * 64 * 3
     assert np.abs(unpack_accum_words(words, 37, 23) - img).max() <= 2.0 ** -37
+
+
+@pytest.mark.parametrize("scene", SCENES + ["synthetic:3000", "synthetic:40000"])
+def test_device_tree_is_conservative(rt, scene):
+    """Every f32 child box (centre and half extent) and every quantised box contains the f32
+    bounds of all primitives below it, every object that can be hit is in exactly one leaf:
+    the invariant all culling rests on, checked on the host for each tree variant."""
+    import ctypes as C
+    from raytracer_amd import _native as N
+    sc = rt.Scene.generate(scene)
+    objs = sc.objects
+    for env in ({}, {"RTHIP_TREE": "ref"}, {"RTHIP_NO_BIG_LEAF": "1"}, {"RTHIP_SAH_CPRIM": "1.0", "RTHIP_SAH_LEAF": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            bad, nodes, depth = C.c_int64(-1), C.c_int32(0), C.c_int32(0)
+            rc = N.lib().rthip_bvh_validate(objs.ctypes.data, len(objs), C.byref(bad), C.byref(nodes), C.byref(depth))
+            assert rc == 0 and bad.value == 0, (scene, env, N.lib().rthip_last_error(None))
+            assert nodes.value >= 1 and 1 <= depth.value <= 32
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
