@@ -19,7 +19,8 @@
 // share an XCD's L2 work on one band) and keeps its 64 lanes busy by handing finished lanes the
 // next paths of the wave's pool (ballot + mbcnt ranking), so lanes are not tied to pixels.  A
 // lane is a small state machine: IDLE -> FRESH -> TRAVERSE -> SHADE -> (FRESH | IDLE).  The wave
-// alternates between shading, regeneration (once enough lanes are idle), ray set-up, and a
+// alternates between shading, regeneration (once enough lanes are idle), ray set-up (which
+// includes the test of the scene's oversized primitives for all starting lanes together), and a
 // traversal loop, which it leaves once the number of lanes still traversing drops under a
 // threshold while the other steps have lanes to serve; lanes interrupted mid-traversal keep
 // their stack and simply continue on the next round.  The per-lane

@@ -1,11 +1,12 @@
 // layout.hpp — the scene as it lies in HBM (and, for small scenes, in LDS).
 //
-// The tree is binary and reference-shaped (median split, leaves of 1..5 objects), but it is
-// stored "children in the parent": an inner node holds the boxes of BOTH children, so one
-// 64-byte fetch (f32) decides where a ray goes next and leaves are never fetched as nodes.
-// Primitives are stored in leaf order, 32 bytes each (f32), spheres before cubes inside a
-// leaf so that the leaf loop has no per-primitive type branch.  Materials are indexed by
-// object id and fetched once per ray, at shading time.
+// The tree is binary (a surface-area build by default; the reference's median split on
+// request) and stored "children in the parent": an inner node holds the boxes of BOTH
+// children, so one 64-byte fetch (f32) decides where a ray goes next and leaves are never
+// fetched as nodes.  Primitives are stored in leaf order, 32 bytes each (f32), spheres before
+// cubes inside a leaf so that the leaf loop has no per-primitive type branch.  A few primitives
+// that dwarf the rest (ground slab, sun) form the first leaf, which every ray tests before it
+// enters the tree.  Materials are indexed by object id and fetched once per ray, at shading time.
 #pragma once
 #include <cstdint>
 
