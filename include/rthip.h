@@ -172,8 +172,10 @@ int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* id
  * contains the f32 bounds of all primitives below it, that every object that can be hit sits
  * in exactly one leaf, and that the depth is as reported.  violations = 0 and RTHIP_OK when
  * sound; otherwise RTHIP_ERR_STATE and rthip_last_error(NULL) describes the first violation.
- * Any output pointer may be NULL. */
-int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* violations, int32_t* n_nodes, int32_t* depth);
+ * checksum receives a hash of every array the device would be given (the build is
+ * deterministic, on one thread or several).  Any output pointer may be NULL. */
+int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* violations, int32_t* n_nodes, int32_t* depth,
+                           uint64_t* checksum);
 
 /* Seeded scene factories (no GPU needed).  Same distributions as the reference's factories,
  * which draw from an OS-seeded generator and are therefore not reproducible themselves:

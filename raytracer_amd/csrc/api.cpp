@@ -687,7 +687,7 @@ int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* id
 	return RTHIP_OK;
 }
 
-int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* violations, int32_t* n_nodes, int32_t* depth) {
+int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* violations, int32_t* n_nodes, int32_t* depth, uint64_t* checksum) {
 	if (n < 0 || (n > 0 && !objects)) return fail(nullptr, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
 	if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
 	FlatScene flat;
@@ -698,6 +698,7 @@ int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* viol
 	if (violations) *violations = bad;
 	if (n_nodes) *n_nodes = (int32_t)flat.nodes32.size();
 	if (depth) *depth = flat.depth;
+	if (checksum) *checksum = checksum_flat_scene(flat);
 	if (bad) return fail(nullptr, RTHIP_ERR_STATE, first);
 	return RTHIP_OK;
 }

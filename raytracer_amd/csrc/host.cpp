@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <functional>
+#include <future>
+#include <map>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -301,6 +303,7 @@ struct Builder {
 	FlatScene* out;
 	int max_depth = 0;
 	int max_leaf = 4;
+	bool threads_on = true;  // large ranges are built on several threads (same result as on one)
 	int sweep_max = 48;  // exact sweep over sorted centroids up to this many primitives, 32 bins beyond
 	double cost_node = 1.0, cost_prim = 0.4;  // a primitive test against a node visit (two box tests); tuned on MI355X
 
@@ -357,8 +360,26 @@ struct Builder {
 	}
 
 	// ---- reference tree: src/bvh.rs:17-81 ------------------------------------------------
-	std::vector<std::pair<double, int32_t>> sort_keys;  // scratch of ref_build
+	// Node count of the reference's tree over `len` objects: fixed by len alone (split at len / 2,
+	// leaves of fewer than six), so every subtree knows its slice of ref_nodes in advance and the
+	// two halves of a large range can be built by different threads.
+	std::map<size_t, size_t> ref_count_memo;
+	size_t ref_count(size_t len) {
+		if (len < 6) return 1;
+		auto it = ref_count_memo.find(len);
+		if (it != ref_count_memo.end()) return it->second;
+		size_t v = 1 + ref_count(len / 2) + ref_count(len - len / 2);
+		ref_count_memo[len] = v;
+		return v;
+	}
+	size_t ref_count_ro(size_t len) const { return len < 6 ? 1 : ref_count_memo.at(len); }
 	int ref_build(size_t begin, size_t end) {
+		ref_count(end - begin);  // fills the memo for every length that occurs below
+		ref_nodes.assign(ref_count_ro(end - begin), RefNode{0, 0, -1, -1, empty_box()});
+		return ref_build_at(begin, end, 0, 0);
+	}
+	int ref_build_at(size_t begin, size_t end, size_t me_index, int depth) {
+		static thread_local std::vector<std::pair<double, int32_t>> sort_keys;  // scratch, free again before the recursion
 		size_t len = end - begin;
 		// :28-47: the axis of largest extent of the cached boxes; the first such axis on ties
 		// (sort_unstable_by leaves that open; a three-element sort keeps input order).
@@ -382,10 +403,31 @@ struct Builder {
 			int32_t id = order[begin + i];
 			sort_keys[i] = {ref_min(id, axis) + ref_max(id, axis), id};
 		}
-		std::stable_sort(sort_keys.begin(), sort_keys.end(), [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) { return a.first < b.first; });
+		auto by_key = [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) { return a.first < b.first; };
+		if (threads_on && len >= 131072 && depth < 3) {
+			// the few largest ranges: eight slices sorted side by side, then merged pairwise (stable
+			// throughout, so the result is the one the plain sort gives)
+			constexpr size_t kSlices = 8;
+			auto* keys = sort_keys.data();
+			size_t cut[kSlices + 1];
+			for (size_t k = 0; k <= kSlices; k++) cut[k] = len * k / kSlices;
+			std::vector<std::future<void>> jobs;
+			for (size_t k = 0; k < kSlices; k++) jobs.push_back(std::async(std::launch::async, [=] { std::stable_sort(keys + cut[k], keys + cut[k + 1], by_key); }));
+			for (auto& j : jobs) j.get();
+			for (size_t width = 1; width < kSlices; width *= 2) {
+				jobs.clear();
+				for (size_t k = 0; k + width < kSlices + 1 && k < kSlices; k += 2 * width) {
+					const size_t a = cut[k], m = cut[std::min(k + width, kSlices)], e = cut[std::min(k + 2 * width, kSlices)];
+					jobs.push_back(std::async(std::launch::async, [=] { std::inplace_merge(keys + a, keys + m, keys + e, by_key); }));
+				}
+				for (auto& j : jobs) j.get();
+			}
+		} else {
+			std::stable_sort(sort_keys.begin(), sort_keys.end(), by_key);
+		}
 		for (size_t i = 0; i < len; i++) order[begin + i] = sort_keys[i].second;
-		int me = (int)ref_nodes.size();
-		ref_nodes.push_back(RefNode{begin, end, -1, -1, empty_box()});
+		int me = (int)me_index;
+		ref_nodes[(size_t)me] = RefNode{begin, end, -1, -1, empty_box()};
 		if (len < 6) {  // :52-61
 			Box ref = ref_box(order[begin]);
 			for (size_t i = begin + 1; i < end; i++) ref = box_union(ref, ref_box(order[i]));
@@ -393,8 +435,16 @@ struct Builder {
 			return me;
 		}
 		size_t mid = begin + len / 2;  // :62-79: the upper half is the right child
-		int l = ref_build(begin, mid);
-		int r = ref_build(mid, end);
+		const size_t left_index = me_index + 1, right_index = left_index + ref_count_ro(mid - begin);
+		int l, r;
+		if (threads_on && len >= 32768 && depth < 5) {  // disjoint slices of order[] and ref_nodes[]: the halves do not meet
+			auto left = std::async(std::launch::async, [=] { return ref_build_at(begin, mid, left_index, depth + 1); });
+			r = ref_build_at(mid, end, right_index, depth + 1);
+			l = left.get();
+		} else {
+			l = ref_build_at(begin, mid, left_index, depth + 1);
+			r = ref_build_at(mid, end, right_index, depth + 1);
+		}
 		ref_nodes[(size_t)me].left = l;
 		ref_nodes[(size_t)me].right = r;
 		ref_nodes[(size_t)me].ref = box_union(ref_nodes[(size_t)l].ref, ref_nodes[(size_t)r].ref);
@@ -448,9 +498,47 @@ struct Builder {
 	// ---- device tree ---------------------------------------------------------------------
 	struct Sub { int32_t code; Box b64, b32; };
 
+	// Where nodes and primitives are appended.  Normally the scene itself; a thread that builds one
+	// half of a large range appends to a list of its own, which is spliced in afterwards in the
+	// order a single thread would have produced (node, left subtree, right subtree).
+	struct Sink {
+		std::vector<Node<double>> n64;
+		std::vector<Node<float>> n32;
+		std::vector<Prim<double>> p64;
+		std::vector<Prim<float>> p32;
+		int max_depth = 0;
+	};
+	static Sink*& local_sink() { static thread_local Sink* s = nullptr; return s; }
+	std::vector<Node<double>>& nodes64() { return local_sink() ? local_sink()->n64 : out->nodes64; }
+	std::vector<Node<float>>& nodes32() { return local_sink() ? local_sink()->n32 : out->nodes32; }
+	std::vector<Prim<double>>& prims64() { return local_sink() ? local_sink()->p64 : out->prims64; }
+	std::vector<Prim<float>>& prims32() { return local_sink() ? local_sink()->p32 : out->prims32; }
+	int& deepest() { return local_sink() ? local_sink()->max_depth : max_depth; }
+	static int32_t rebase(int32_t code, int32_t node_base, int32_t prim_base) {
+		if (code >= 0) return code + node_base;
+		const uint32_t c = ~(uint32_t)code;
+		return (int32_t)~((((c >> 6) + (uint32_t)prim_base) << 6) | (c & 63u));
+	}
+	// Appends what a finished thread built to the current sink; returns its root in the new numbering.
+	Sub splice(Sink& part, Sub root) {
+		const int32_t node_base = (int32_t)nodes64().size(), prim_base = (int32_t)prims64().size();
+		for (size_t i = 0; i < part.n64.size(); i++)
+			for (int c = 0; c < 2; c++) {
+				part.n64[i].child[c] = rebase(part.n64[i].child[c], node_base, prim_base);
+				part.n32[i].child[c] = part.n64[i].child[c];
+			}
+		nodes64().insert(nodes64().end(), part.n64.begin(), part.n64.end());
+		nodes32().insert(nodes32().end(), part.n32.begin(), part.n32.end());
+		prims64().insert(prims64().end(), part.p64.begin(), part.p64.end());
+		prims32().insert(prims32().end(), part.p32.begin(), part.p32.end());
+		if (part.max_depth > deepest()) deepest() = part.max_depth;
+		root.code = rebase(root.code, node_base, prim_base);
+		return root;
+	}
+
 	void write_node(int32_t me, const Sub& l, const Sub& r) {
-		Node<double>& n64 = out->nodes64[(size_t)me];
-		Node<float>& n32 = out->nodes32[(size_t)me];
+		Node<double>& n64 = nodes64()[(size_t)me];
+		Node<float>& n32 = nodes32()[(size_t)me];
 		const Sub* ch[2] = {&l, &r};
 		for (int c = 0; c < 2; c++) {
 			for (int k = 0; k < 3; k++) {
@@ -476,14 +564,14 @@ struct Builder {
 		}
 	}
 	int32_t new_node() {
-		out->nodes64.emplace_back();
-		out->nodes32.emplace_back();
-		return (int32_t)out->nodes64.size() - 1;
+		nodes64().emplace_back();
+		nodes32().emplace_back();
+		return (int32_t)nodes64().size() - 1;
 	}
 	// Appends the primitives ids[0..k) as one leaf: spheres first, then cubes, so the leaf loop
 	// has no per-primitive type branch.
 	Sub emit_leaf(const int32_t* ids, int k) {
-		int32_t first = (int32_t)out->prims64.size();
+		int32_t first = (int32_t)prims64().size();
 		Box b64 = empty_box(), b32 = empty_box();
 		int ns = 0, nc = 0;
 		for (int pass = 0; pass < 2; pass++) {
@@ -512,8 +600,8 @@ struct Builder {
 				}
 				p64.id = p32.id = id | (o.material << kMatShift) | (o.kind << kKindShift);
 				p64.rank = p32.rank = rank[(size_t)id];
-				out->prims64.push_back(p64);
-				out->prims32.push_back(p32);
+				prims64().push_back(p64);
+				prims32().push_back(p32);
 				b64 = box_union(b64, bounds64(id));
 				b32 = box_union(b32, bounds32(id));
 			}
@@ -534,7 +622,7 @@ struct Builder {
 		Sub l = shape_ref(n.left, depth + 1);
 		Sub r = shape_ref(n.right, depth + 1);
 		write_node(me, l, r);
-		if (depth + 1 > max_depth) max_depth = depth + 1;
+		if (depth + 1 > deepest()) deepest() = depth + 1;
 		return Sub{me, box_union(l.b64, r.b64), box_union(l.b32, r.b32)};
 	}
 
@@ -638,10 +726,29 @@ struct Builder {
 		}
 		(void)best_left;
 		int32_t me = new_node();
-		Sub l = sah_build(begin, mid, depth + 1);
-		Sub r = sah_build(mid, end, depth + 1);
+		Sub l, r;
+		if (threads_on && n >= 32768 && depth < 5) {
+			// the halves are disjoint slices of items[]: build them side by side, each into a list of its own
+			Sink left_part, right_part;
+			auto left = std::async(std::launch::async, [&, begin, mid, depth] {
+				local_sink() = &left_part;
+				Sub sub = sah_build(begin, mid, depth + 1);
+				local_sink() = nullptr;
+				return sub;
+			});
+			Sink* mine = local_sink();
+			local_sink() = &right_part;
+			r = sah_build(mid, end, depth + 1);
+			local_sink() = mine;
+			l = left.get();
+			l = splice(left_part, l);
+			r = splice(right_part, r);
+		} else {
+			l = sah_build(begin, mid, depth + 1);
+			r = sah_build(mid, end, depth + 1);
+		}
 		write_node(me, l, r);
-		if (depth + 1 > max_depth) max_depth = depth + 1;
+		if (depth + 1 > deepest()) deepest() = depth + 1;
 		return Sub{me, box_union(l.b64, r.b64), box_union(l.b32, r.b32)};
 	}
 };
@@ -681,6 +788,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		t_start = now;
 	};
 	// 1. the reference's tree: ranks, leaf order, gates
+	if (const char* v = std::getenv("RTHIP_BUILD_THREADS")) b.threads_on = std::atoi(v) != 1;
 	int ref_root = b.ref_build(0, (size_t)n);
 	lap("reference tree");
 	{
@@ -879,6 +987,24 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		if (!ok) out->qnodes.clear();  // cannot happen with the headroom above; the full nodes are always valid
 	}
 	return true;
+}
+
+uint64_t checksum_flat_scene(const FlatScene& s) {
+	uint64_t h = 1469598103934665603ull;
+	auto mix = [&](const void* p, size_t n) {
+		const unsigned char* b = static_cast<const unsigned char*>(p);
+		for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+	};
+	// field by field: the structs have padding bytes that hold nothing
+	for (const auto& n : s.nodes32) { mix(n.box, sizeof(n.box)); mix(n.child, sizeof(n.child)); }
+	for (const auto& n : s.nodes64) { mix(n.box, sizeof(n.box)); mix(n.child, sizeof(n.child)); }
+	for (const auto& p : s.prims32) { mix(p.v, sizeof(p.v)); mix(&p.id, 4); mix(&p.rank, 4); }
+	for (const auto& p : s.prims64) { mix(p.v, sizeof(p.v)); mix(&p.id, 4); mix(&p.rank, 4); }
+	for (const auto& q : s.qnodes) { mix(q.q, sizeof(q.q)); mix(q.child, sizeof(q.child)); }
+	for (const auto& g : s.gates64) mix(g.box, sizeof(g.box));
+	mix(s.leaf_ids.data(), s.leaf_ids.size() * 4);
+	mix(&s.depth, sizeof(s.depth));
+	return h;
 }
 
 int64_t validate_flat_scene(const FlatScene& s, int64_t n_objects, std::string* first) {

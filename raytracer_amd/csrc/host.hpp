@@ -51,5 +51,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 // primitive that can be hit is in exactly one leaf; the tree is no deeper than reported.
 // Returns the number of violations (0 = sound) and describes the first one.
 int64_t validate_flat_scene(const FlatScene& s, int64_t n_objects, std::string* first);
+// FNV-1a over everything the device would receive: equal scenes, equal builds, equal value.
+uint64_t checksum_flat_scene(const FlatScene& s);
 
 }  // namespace rthip

@@ -174,10 +174,29 @@ def test_device_tree_is_conservative(rt, scene):
         os.environ.update(env)
         try:
             bad, nodes, depth = C.c_int64(-1), C.c_int32(0), C.c_int32(0)
-            rc = N.lib().rthip_bvh_validate(objs.ctypes.data, len(objs), C.byref(bad), C.byref(nodes), C.byref(depth))
+            rc = N.lib().rthip_bvh_validate(objs.ctypes.data, len(objs), C.byref(bad), C.byref(nodes), C.byref(depth), None)
             assert rc == 0 and bad.value == 0, (scene, env, N.lib().rthip_last_error(None))
             assert nodes.value >= 1 and 1 <= depth.value <= 32
         finally:
             for k, v in old.items():
                 if v is None: os.environ.pop(k, None)
                 else: os.environ[k] = v
+
+
+def test_threaded_build_equals_single_threaded(rt):
+    """Ranges of 32 k objects and more are built on several threads (reference tree and surface-area
+    tree alike); every array handed to the device is the same as from one thread."""
+    import ctypes as C
+    from raytracer_amd import _native as N
+    objs = rt.create_synthetic_scene(150000, seed=7).objects
+    sums = []
+    for threads in ("1", "0"):
+        os.environ["RTHIP_BUILD_THREADS"] = threads
+        try:
+            bad, h = C.c_int64(-1), C.c_uint64(0)
+            rc = N.lib().rthip_bvh_validate(objs.ctypes.data, len(objs), C.byref(bad), None, None, C.byref(h))
+            assert rc == 0 and bad.value == 0, N.lib().rthip_last_error(None)
+            sums.append(h.value)
+        finally:
+            os.environ.pop("RTHIP_BUILD_THREADS", None)
+    assert sums[0] == sums[1] and sums[0] != 0
