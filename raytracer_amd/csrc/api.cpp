@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -106,6 +107,19 @@ int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const st
 	b->prims_off = (uint32_t)prims_off; b->mats_off = (uint32_t)mats_off; b->gates_off = (uint32_t)gates_off; b->bytes = (uint32_t)total;
 	b->lds_bytes = (uint32_t)mats_off;
 	return RTHIP_OK;
+}
+
+// The host build allocates and starts threads; nothing it throws may cross the C ABI.
+bool build_scene_guarded(const rthip_object* objects, int64_t n, FlatScene* flat, std::string* err) {
+	try {
+		return build_flat_scene(objects, n, flat, err);
+	} catch (const std::exception& e) {
+		*err = std::string("scene build failed: ") + e.what();
+	} catch (...) {
+		*err = "scene build failed";
+	}
+	flat->depth = kStackMax + 1;  // reported as RTHIP_ERR_LIMIT
+	return false;
 }
 
 int env_int(const char* name, int dflt) {
@@ -412,7 +426,7 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	FlatScene flat;
 	std::string err;
-	if (!build_flat_scene(objects, n, &flat, &err)) return fail(c, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+	if (!build_scene_guarded(objects, n, &flat, &err)) return fail(c, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
 	c->has_scene = false;
 	int32_t rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32, &flat.qnodes, &flat.qframe);
 	if (rc != RTHIP_OK) return rc;
@@ -679,7 +693,7 @@ int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* id
 	if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
 	FlatScene flat;
 	std::string err;
-	if (!build_flat_scene(objects, n, &flat, &err)) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+	if (!build_scene_guarded(objects, n, &flat, &err)) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
 	if (ids) std::copy(flat.leaf_ids.begin(), flat.leaf_ids.end(), ids);
 	if (leaf_sizes) std::copy(flat.leaf_sizes.begin(), flat.leaf_sizes.end(), leaf_sizes);
 	if (n_leaves) *n_leaves = (int64_t)flat.leaf_sizes.size();
@@ -692,7 +706,7 @@ int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* viol
 	if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
 	FlatScene flat;
 	std::string err;
-	if (!build_flat_scene(objects, n, &flat, &err)) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+	if (!build_scene_guarded(objects, n, &flat, &err)) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
 	std::string first;
 	const int64_t bad = validate_flat_scene(flat, n, &first);
 	if (violations) *violations = bad;
