@@ -67,6 +67,7 @@ struct RenderArgs {
 	int32_t part_index, part_count;
 	uint32_t n_items, chunk, n_chunks;
 	int32_t trav_threshold;
+	uint32_t block_order;   // nonzero: work items run through the image in blocks of 16x16 tiles (scenes in global memory)
 	int32_t regen_min;      // regenerate paths only when at least this many lanes are idle (or all are)
 	int32_t inner_exit;     // sixteenths: leave the inner-node loop when fewer lanes than this share of the round remain in it
 	unsigned long long* accum;    // [tiles][3 channels][64 px] fixed point
@@ -725,10 +726,25 @@ RT_FN void accumulate_sample(unsigned long long* accum, uint32_t accum_index, V3
 // samples).  Returns false for pixels outside the image and samples beyond spp_count.
 struct PathId { uint32_t px, py, accum_index, s_local; };
 __device__ __forceinline__ bool decode_path(uint32_t item, uint32_t j, uint32_t n_chunks, uint32_t chunk, uint32_t spp_count,
-                                            int32_t part_index, int32_t part_count, int32_t tiles_x, int32_t width, int32_t height, PathId* out) {
+                                            int32_t part_index, int32_t part_count, int32_t tiles_x, int32_t width, int32_t height, PathId* out, uint32_t block_order = 0u) {
 	uint32_t tile_local = item / n_chunks, chunk_i = item - tile_local * n_chunks;
 	uint32_t tile = (uint32_t)part_index + tile_local * (uint32_t)part_count;
 	uint32_t ty = tile / (uint32_t)tiles_x, tx = tile - ty * (uint32_t)tiles_x;
+	if (block_order != 0u && part_count == 1) {
+		// Work order in blocks of 16x16 tiles (row-major inside a block, blocks row-major): the
+		// waves at work at one time then look at a compact part of the scene, which is what the
+		// L2 of an XCD can hold of a tree that lives in memory.  The tile's place in the
+		// accumulation buffer does not change.
+		const uint32_t S = 16u, tiles_y = ((uint32_t)height + kTile - 1u) / kTile;
+		const uint32_t band = tile_local / ((uint32_t)tiles_x * S), r = tile_local - band * (uint32_t)tiles_x * S;
+		const uint32_t h = min(S, tiles_y - band * S);
+		const uint32_t n_cols = ((uint32_t)tiles_x + S - 1u) / S;
+		const uint32_t sx = min(r / (S * h), n_cols - 1u), rr = r - sx * S * h;
+		const uint32_t w = min(S, (uint32_t)tiles_x - sx * S);
+		const uint32_t ly = rr / w, lx = rr - ly * w;
+		tx = sx * S + lx; ty = band * S + ly;
+		tile = ty * (uint32_t)tiles_x + tx;
+	}
 	out->px = tx * kTile + (j & 7u);
 	out->py = ty * kTile + ((j >> 3) & 7u);
 	out->s_local = chunk_i * chunk + (j >> 6);
@@ -841,7 +857,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				uint32_t rk = lane_rank(need);
 				if (rk < take) {
 					PathId id;
-					if (decode_path(item, pool_pos + rk, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id)) {
+					if (decode_path(item, pool_pos + rk, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds ? 0u : A.block_order)) {
 						rng.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
 						RayT<Real> r = camera_ray<Real>(A.cam, (Real)id.px, (Real)id.py, rng, true);
 						accum_index = id.accum_index;
