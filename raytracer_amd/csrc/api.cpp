@@ -233,7 +233,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.n_items = plan.n_items; a.chunk = plan.chunk; a.n_chunks = plan.n_chunks; a.trav_threshold = plan.threshold;
 	a.inner_exit = env_int("RTHIP_INNER_EXIT", plan.cfg.scene_in_lds ? 5 : 8);
 	a.regen_min = std::max(1, std::min(64, env_int("RTHIP_REGEN_MIN", 16)));
-	a.block_order = (uint32_t)env_int("RTHIP_BLOCK_ORDER", 1);
+	a.block_order = (uint32_t)std::max(0, std::min(1024, env_int("RTHIP_BLOCK_ORDER", 32)));
 	a.accum = accum; a.samples_out = samples_out;
 	a.queue = reinterpret_cast<uint32_t*>(c->d_control + 512);
 	a.stats = reinterpret_cast<unsigned long long*>(c->d_control + 8);

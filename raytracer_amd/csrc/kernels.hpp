@@ -67,7 +67,7 @@ struct RenderArgs {
 	int32_t part_index, part_count;
 	uint32_t n_items, chunk, n_chunks;
 	int32_t trav_threshold;
-	uint32_t block_order;   // nonzero: work items run through the image in blocks of 16x16 tiles (scenes in global memory)
+	uint32_t block_order;   // S > 0: work items run through the image in blocks of S x S tiles (scenes in global memory)
 	int32_t regen_min;      // regenerate paths only when at least this many lanes are idle (or all are)
 	int32_t inner_exit;     // sixteenths: leave the inner-node loop when fewer lanes than this share of the round remain in it
 	unsigned long long* accum;    // [tiles][3 channels][64 px] fixed point
@@ -731,11 +731,11 @@ __device__ __forceinline__ bool decode_path(uint32_t item, uint32_t j, uint32_t 
 	uint32_t tile = (uint32_t)part_index + tile_local * (uint32_t)part_count;
 	uint32_t ty = tile / (uint32_t)tiles_x, tx = tile - ty * (uint32_t)tiles_x;
 	if (block_order != 0u && part_count == 1) {
-		// Work order in blocks of 16x16 tiles (row-major inside a block, blocks row-major): the
+		// Work order in blocks of block_order x block_order tiles (32 by default; row-major inside a block, blocks row-major): the
 		// waves at work at one time then look at a compact part of the scene, which is what the
 		// L2 of an XCD can hold of a tree that lives in memory.  The tile's place in the
 		// accumulation buffer does not change.
-		const uint32_t S = 16u, tiles_y = ((uint32_t)height + kTile - 1u) / kTile;
+		const uint32_t S = block_order, tiles_y = ((uint32_t)height + kTile - 1u) / kTile;
 		const uint32_t band = tile_local / ((uint32_t)tiles_x * S), r = tile_local - band * (uint32_t)tiles_x * S;
 		const uint32_t h = min(S, tiles_y - band * S);
 		const uint32_t n_cols = ((uint32_t)tiles_x + S - 1u) / S;
