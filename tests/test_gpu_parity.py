@@ -475,3 +475,20 @@ def test_tree_fineness_follows_the_lds_budget(rt):
         per_block = s["n_nodes"] * 64 + s["n_prims"] * 32 + s["tree_depth"] * 512 * 4
         assert per_block <= 160 * 1024 // blocks, (n, s["n_nodes"], s["tree_depth"])
         r.close()
+
+
+@pytest.mark.gpu
+def test_tile_block_order_changes_no_image(rt, monkeypatch):
+    """Scenes in global memory run their work items through the image in blocks of tiles; the
+    order (any block size, ragged image edges included) changes no accumulated word."""
+    cam = rt.Camera((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0, 701, 333)
+    r = rt.Renderer(rt.create_synthetic_scene(5000, seed=3), cam, max_depth=8, seed=9)
+    images = []
+    for block in ("0", "32", "5", "1", "1000"):
+        monkeypatch.setenv("RTHIP_BLOCK_ORDER", block)
+        r.reset_accumulation(); r.accumulate(3)
+        assert r.stats()["scene_in_lds"] == 0
+        images.append(r.read_accum())
+    for img in images[1:]:
+        assert np.array_equal(img, images[0])
+    r.close()
