@@ -29,12 +29,14 @@ enum {
 	RTHIP_ERR_EMPTY = 2,    /* empty scene: BVH::new returns None (src/bvh.rs:51) */
 	RTHIP_ERR_STATE = 3,    /* scene or camera not set yet */
 	RTHIP_ERR_HIP = 4,      /* a HIP runtime call failed; see rthip_last_error */
-	RTHIP_ERR_LIMIT = 5     /* tree deeper than the traversal stack, image too large, ... */
+	RTHIP_ERR_LIMIT = 5,    /* tree deeper than the traversal stack, image too large, out of host memory, ... */
+	RTHIP_ERR_INTERNAL = 6  /* a C++ exception was caught at the ABI; see rthip_last_error */
 };
 
 enum { RTHIP_SPHERE = 0, RTHIP_CUBE = 1 };                           /* src/scene.rs:36-40 Object */
 enum { RTHIP_LAMBERTIAN = 0, RTHIP_METAL = 1, RTHIP_DIELECTRIC = 2 }; /* src/materials.rs:4-8 */
-enum { RTHIP_F32 = 0, RTHIP_F64 = 1 };
+enum { RTHIP_F32 = 0, RTHIP_F64 = 1,
+       RTHIP_F32_RAW = 2 /* rthip_trace_primary only: f32 hit records without the f64 refinement */ };
 enum { RTHIP_SKY_REFERENCE = 0, RTHIP_SKY_WALLPAPER = 1 };
 enum { RTHIP_MEGAKERNEL = 0, RTHIP_WAVEFRONT = 1 };
 
@@ -87,7 +89,7 @@ typedef struct rthip_stats {
 	double kernel_ms;       /* device time of the last render call's kernels (HIP events) */
 	int32_t n_nodes, n_leaves, n_prims, tree_depth; /* of the uploaded scene */
 	int32_t scene_in_lds;   /* 1 when the last render kept the scene in LDS */
-	int32_t reserved;
+	int32_t n_gates;        /* gate boxes of the uploaded scene (inverted spheres parted from their outer shell) */
 } rthip_stats;
 
 typedef struct rthip_ctx rthip_ctx;
@@ -99,6 +101,17 @@ void rthip_destroy(rthip_ctx* ctx);
 const char* rthip_last_error(const rthip_ctx* ctx);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
+
+/* Tuning and build knobs (no counterpart in the reference, which has no configuration at all).
+ * A context reads the RTHIP_* environment variables ONCE, in rthip_create; this call changes a
+ * knob afterwards.  Names are the variable names in lower case without the prefix: launch knobs
+ * "scene_lds", "qnodes", "threads", "blocks_per_cu", "chunk", "trav_threshold", "inner_exit",
+ * "regen_min", "block_order", "wf_batch", "count" take effect with the next render call; build
+ * knobs "tree_ref" (1 = device tree in the reference's shape), "sah_leaf", "sah_cprim",
+ * "sah_sweep", "big_leaf_min", "no_big_leaf", "no_qnodes", "build_threads", "tie_reverse"
+ * (1 = equal sort keys of BVH::new in reversed order, see rthip_bvh_leaf_order) with the next
+ * rthip_scene_upload.  Unknown names return RTHIP_ERR_INVALID. */
+int32_t rthip_set_option(rthip_ctx* ctx, const char* name, double value);
 
 /* Replaces BVH::new(scene) (src/bvh.rs:17-81): builds the reference-shaped median-split
  * tree on the host, flattens it and uploads nodes, primitives and materials to HBM.
@@ -121,6 +134,19 @@ int32_t rthip_render_accumulate(rthip_ctx* ctx, const rthip_render_params* p);
  * after rthip_synchronize. */
 int32_t rthip_render_accumulate_async(rthip_ctx* ctx, const rthip_render_params* p);
 int32_t rthip_synchronize(rthip_ctx* ctx);
+/* The asynchronous render call for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart
+ * in the reference.  It calls no hipMalloc, hipFree or other allocating routine: the control
+ * block of the launch (work-queue counters and statistics, 1 KiB) lives in a 4 KiB array in
+ * static device memory that every GPU holds from library load to process exit, instead of the
+ * block rthip_create allocates.  Limits: RTHIP_MEGAKERNEL only (the wavefront variant needs
+ * gigabytes of path state: RTHIP_ERR_LIMIT); the accumulation buffer of the current image size
+ * must already exist (rthip_camera_set or rthip_set_accum_buffer: RTHIP_ERR_STATE otherwise,
+ * nothing is allocated for it).  All contexts on one GPU share that GPU's array and the array
+ * keeps the last call's contents (the call clears what must start at zero, in stream order):
+ * calls that overlap in time on one GPU, from two contexts or two streams, race.  Same
+ * results, bit for bit, as rthip_render_accumulate_async. */
+int32_t rthip_render_accumulate_noalloc(rthip_ctx* ctx, const rthip_render_params* p);
 /* raytracer_runtime/src/main.rs:102-103 (accum_image cleared on a camera change). */
 int32_t rthip_reset_accumulation(rthip_ctx* ctx);
 
@@ -165,6 +191,13 @@ int32_t rthip_get_stats(rthip_ctx* ctx, rthip_stats* out);
  * leaf_sizes at most n; any output pointer may be NULL. */
 int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* ids, int32_t* leaf_sizes, int64_t* n_leaves,
                              int32_t* depth);
+
+/* Host-only (no GPU needed): how many gate boxes the build attaches, and to how many spheres.
+ * A sphere of negative radius caches an inverted box (src/shapes/sphere.rs:13-19) that adds
+ * nothing to the boxes BVH::new unions above it (src/bvh.rs:53-56,68); where a split parts it
+ * from its outer shell, the reference reaches it only through boxes smaller than the sphere,
+ * and those boxes travel with it as gates.  Any output pointer may be NULL. */
+int32_t rthip_bvh_gate_count(const rthip_object* objects, int64_t n, int64_t* n_gates, int64_t* n_gated_spheres);
 
 /* Host-only self-check (no counterpart in the reference: its tree is never wrong by construction,
  * this one is conservative by rounding rules that deserve a test).  Builds the device tree as

@@ -51,6 +51,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.oracle_scene_create.restype = C.c_void_p
         L.oracle_scene_create.argtypes = [C.c_void_p, C.c_int64]
+        L.oracle_scene_create_ordered.restype = C.c_void_p
+        L.oracle_scene_create_ordered.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
         L.oracle_bvh_depth.restype = C.c_int32
         L.oracle_bvh_depth.argtypes = [C.c_void_p]
@@ -107,9 +109,11 @@ def camera_desc(origin, direction, fov, focus_dist, defocus_angle, width, height
 class OracleScene:
     """A scene with its reference-shaped BVH built (oracle_scene_create)."""
 
-    def __init__(self, objects):
+    def __init__(self, objects, tie_reverse=False):
+        """tie_reverse: objects with equal sort keys in BVH::new end up in reversed instead of kept
+        order (the reference's sort_unstable_by, src/bvh.rs:49, leaves their order open)."""
         self.objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
-        self._h = lib().oracle_scene_create(self.objects.ctypes.data, len(self.objects))
+        self._h = lib().oracle_scene_create_ordered(self.objects.ctypes.data, len(self.objects), int(bool(tie_reverse)))
         if not self._h:
             raise ValueError("empty scene: BVH::new returns None")
 

@@ -360,7 +360,9 @@ static inline AABB true_bounds(const Object& o) {
 }
 // bvh.rs:17-81.  sort_unstable_by leaves the order of equal keys unspecified; this build
 // fixes it as a stable sort of the current sequence (and the first axis of maximal range).
-static std::unique_ptr<BVH> bvh_new(std::vector<Object> objects) {
+// tie_reverse = the opposite extreme: equal keys end up in REVERSED order (a stable sort of the
+// reversed sequence), to measure how much the unspecified order can matter.
+static std::unique_ptr<BVH> bvh_new(std::vector<Object> objects, bool tie_reverse = false) {
 	if (objects.empty()) return nullptr;  // :51
 	Scalar range[3];
 	for (int axis = 0; axis < 3; axis++) {  // :28-43
@@ -374,6 +376,7 @@ static std::unique_ptr<BVH> bvh_new(std::vector<Object> objects) {
 	int axis = 0;  // :45-47, descending by range; first maximal axis on ties
 	for (int a = 1; a < 3; a++)
 		if (range[a] > range[axis]) axis = a;
+	if (tie_reverse) std::reverse(objects.begin(), objects.end());
 	std::stable_sort(objects.begin(), objects.end(), [axis](const Object& a, const Object& b) {  // :18-26,49
 		Scalar ac = a.aabb.min[axis] + a.aabb.max[axis];
 		Scalar bc = b.aabb.min[axis] + b.aabb.max[axis];
@@ -397,8 +400,8 @@ static std::unique_ptr<BVH> bvh_new(std::vector<Object> objects) {
 	// :62-79  the upper half goes right, the rest left.
 	std::vector<Object> upper(objects.begin() + len / 2, objects.end());
 	objects.resize(len / 2);
-	node->right = bvh_new(std::move(upper));
-	node->left = bvh_new(std::move(objects));
+	node->right = bvh_new(std::move(upper), tie_reverse);
+	node->left = bvh_new(std::move(objects), tie_reverse);
 	node->is_leaf = false;
 	node->aabb = surrounding(node->left->aabb, node->right->aabb);
 	node->tight = surrounding(node->left->tight, node->right->tight);
@@ -711,7 +714,9 @@ struct oracle_scene {
 	int64_t n_objects;
 };
 
-oracle_scene* oracle_scene_create(const oracle_object* objs, int64_t n) {
+oracle_scene* oracle_scene_create_ordered(const oracle_object* objs, int64_t n, int32_t tie_reverse);
+oracle_scene* oracle_scene_create(const oracle_object* objs, int64_t n) { return oracle_scene_create_ordered(objs, n, 0); }
+oracle_scene* oracle_scene_create_ordered(const oracle_object* objs, int64_t n, int32_t tie_reverse) {
 	std::vector<Object> objects;
 	objects.reserve((size_t)n);
 	for (int64_t i = 0; i < n; i++) {
@@ -725,7 +730,7 @@ oracle_scene* oracle_scene_create(const oracle_object* objs, int64_t n) {
 		o.rank = 0;
 		objects.push_back(o);
 	}
-	std::unique_ptr<BVH> bvh = bvh_new(std::move(objects));
+	std::unique_ptr<BVH> bvh = bvh_new(std::move(objects), tie_reverse != 0);
 	if (!bvh) return nullptr;  // bvh.rs:51 : an empty scene has no BVH
 	int next = 0;
 	assign_ranks(bvh.get(), &next);

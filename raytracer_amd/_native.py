@@ -11,10 +11,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTHIP_LIBRARY") or os.path.join(_HERE, "librthip.so")  # override: A/B builds of the same ABI
 
-OK, ERR_INVALID, ERR_EMPTY, ERR_STATE, ERR_HIP, ERR_LIMIT = 0, 1, 2, 3, 4, 5
+OK, ERR_INVALID, ERR_EMPTY, ERR_STATE, ERR_HIP, ERR_LIMIT, ERR_INTERNAL = 0, 1, 2, 3, 4, 5, 6
 SPHERE, CUBE = 0, 1
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
-F32, F64 = 0, 1
+F32, F64, F32_RAW = 0, 1, 2
 SKY_REFERENCE, SKY_WALLPAPER = 0, 1
 MEGAKERNEL, WAVEFRONT = 0, 1
 
@@ -39,7 +39,7 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("box_tests", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("cube_tests", C.c_uint64), ("kernel_ms", C.c_double), ("n_nodes", C.c_int32), ("n_leaves", C.c_int32),
-                ("n_prims", C.c_int32), ("tree_depth", C.c_int32), ("scene_in_lds", C.c_int32), ("reserved", C.c_int32)]
+                ("n_prims", C.c_int32), ("tree_depth", C.c_int32), ("scene_in_lds", C.c_int32), ("n_gates", C.c_int32)]
 
 
 # Every symbol include/rthip.h declares: name -> (restype, argtypes)
@@ -49,11 +49,13 @@ SYMBOLS = {
     "rthip_destroy": (None, [_P]),
     "rthip_last_error": (C.c_char_p, [_P]),
     "rthip_set_stream": (C.c_int32, [_P, _P]),
+    "rthip_set_option": (C.c_int32, [_P, C.c_char_p, C.c_double]),
     "rthip_scene_upload": (C.c_int32, [_P, _P, C.c_int64]),
     "rthip_camera_set": (C.c_int32, [_P, C.POINTER(CameraDesc)]),
     "rthip_camera_fields": (C.c_int32, [C.POINTER(CameraDesc), C.POINTER(C.c_double)]),
     "rthip_render_accumulate": (C.c_int32, [_P, C.POINTER(RenderParams)]),
     "rthip_render_accumulate_async": (C.c_int32, [_P, C.POINTER(RenderParams)]),
+    "rthip_render_accumulate_noalloc": (C.c_int32, [_P, C.POINTER(RenderParams)]),
     "rthip_synchronize": (C.c_int32, [_P]),
     "rthip_reset_accumulation": (C.c_int32, [_P]),
     "rthip_accum_buffer": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
@@ -67,6 +69,7 @@ SYMBOLS = {
     "rthip_render_samples": (C.c_int32, [_P, C.POINTER(RenderParams), _P]),
     "rthip_get_stats": (C.c_int32, [_P, C.POINTER(Stats)]),
     "rthip_bvh_leaf_order": (C.c_int32, [_P, C.c_int64, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "rthip_bvh_gate_count": (C.c_int32, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rthip_bvh_validate": (C.c_int32, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "rthip_scene_generate": (C.c_int32, [C.c_char_p, C.c_uint32, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "rthip_camera_rotation": (None, [C.c_double, C.c_double, C.POINTER(C.c_double)]),

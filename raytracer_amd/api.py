@@ -135,6 +135,13 @@ class Camera:
         return d
 
 
+def bvh_gate_count(scene):
+    """(gate boxes, gated spheres) of the scene's build (rthip_bvh_gate_count; host only)."""
+    g, s = C.c_int64(0), C.c_int64(0)
+    N.check(N.lib().rthip_bvh_gate_count(scene.objects.ctypes.data, len(scene), C.byref(g), C.byref(s)))
+    return g.value, s.value
+
+
 class BVH:
     """src/bvh.rs:17: BVH::new(scene) -> Option<BVH>.  Host-side view of the tree shape; the
     device copy is made by Renderer."""
@@ -158,10 +165,12 @@ class Renderer:
     / frame counter follow the shape of raytracer_gpu/src/renderer.rs:484-587)."""
 
     def __init__(self, scene, camera, device=0, max_depth=10, seed=0x5EED0001, sky_mode=N.SKY_REFERENCE, precision=N.F32,
-                 variant=N.MEGAKERNEL):
+                 variant=N.MEGAKERNEL, options=None):
         self._lib = N.lib()
         self._ctx = C.c_void_p()
         N.check(self._lib.rthip_create(int(device), C.byref(self._ctx)))
+        for name, value in (options or {}).items():   # build knobs must be set before the scene is uploaded
+            self.set_option(name, value)
         self.max_depth, self.seed, self.sky_mode, self.precision = max_depth, seed, sky_mode, precision
         self.variant = variant  # MEGAKERNEL (persistent threads) or WAVEFRONT (generate / extend / shade per bounce)
         self.spp_done = 0
@@ -191,6 +200,10 @@ class Renderer:
         except Exception:
             pass
 
+    def set_option(self, name, value):
+        """Tuning / build knob by name (rthip_set_option in include/rthip.h)."""
+        self._check(self._lib.rthip_set_option(self._ctx, name.encode(), float(value)))
+
     def set_stream(self, stream_handle):
         self._check(self._lib.rthip_set_stream(self._ctx, C.c_void_p(stream_handle)))
 
@@ -212,12 +225,18 @@ class Renderer:
         p.part_index, p.part_count = part
         return p
 
-    def accumulate(self, spp, part=(0, 1), spp_begin=None, sync=True):
-        """Adds `spp` samples per pixel (samples spp_begin .. spp_begin+spp of the stream)."""
+    def accumulate(self, spp, part=(0, 1), spp_begin=None, sync=True, noalloc=False):
+        """Adds `spp` samples per pixel (samples spp_begin .. spp_begin+spp of the stream).
+        noalloc: through rthip_render_accumulate_noalloc, the entry point that allocates nothing."""
         begin = self.spp_done if spp_begin is None else spp_begin
         p = self._params(begin, spp, part)
-        fn = self._lib.rthip_render_accumulate if sync else self._lib.rthip_render_accumulate_async
-        self._check(fn(self._ctx, C.byref(p)))
+        if noalloc:
+            self._check(self._lib.rthip_render_accumulate_noalloc(self._ctx, C.byref(p)))
+            if sync:
+                self.synchronize()
+        else:
+            fn = self._lib.rthip_render_accumulate if sync else self._lib.rthip_render_accumulate_async
+            self._check(fn(self._ctx, C.byref(p)))
         if spp_begin is None:
             self.spp_done += spp
 

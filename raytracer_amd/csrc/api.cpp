@@ -7,7 +7,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <map>
+#include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rthip.h"
@@ -27,6 +30,45 @@ struct SceneBlob {  // one precision of the scene in HBM: [nodes | prims | mats]
 	QFrame qframe{};
 };
 inline uint32_t align_up(uint64_t v, uint32_t a) { return (uint32_t)((v + a - 1) / a * a); }
+
+int env_int(const char* name, int dflt) {
+	const char* v = std::getenv(name);
+	return (v && *v) ? std::atoi(v) : dflt;
+}
+
+// Launch-time knobs.  Read from the RTHIP_* environment ONCE, when the context is created (a
+// library under a threaded host must not call getenv per launch: it races with setenv, and the
+// kernel's behaviour would follow the ambient environment); rthip_set_option changes them later.
+struct Tuning {
+	int scene_lds = -1;       // RTHIP_SCENE_LDS: -1 = by size, 0 = never, 1 = whenever it fits 100 KB
+	int qnodes = 1;           // RTHIP_QNODES: traverse the quantised nodes of large f32 scenes
+	int threads = 0;          // RTHIP_THREADS: force the workgroup size (256, 512, 1024), 0 = most resident waves
+	int blocks_per_cu = 0;    // RTHIP_BLOCKS_PER_CU: cap on resident workgroups per CU, 0 = none
+	int chunk = 0;            // RTHIP_CHUNK: samples of a tile per work item, 0 = by launch size
+	int trav_threshold = -1;  // RTHIP_TRAV_THRESHOLD: -1 = 14 (scene in LDS) / 36 (global memory)
+	int inner_exit = -1;      // RTHIP_INNER_EXIT: sixteenths, -1 = 5 (LDS) / 8 (global memory)
+	int regen_min = 16;       // RTHIP_REGEN_MIN
+	int block_order = 32;     // RTHIP_BLOCK_ORDER
+	int wf_batch = 64 << 20;  // RTHIP_WF_BATCH: paths per batch of the wavefront variant
+	int count = 0;            // RTHIP_COUNT: instrumented launches (test tallies, region counters)
+	std::string region_dump;  // RTHIP_REGION_DUMP: file that instrumented runs append region utilisation to
+	static Tuning from_env() {
+		Tuning t;
+		t.scene_lds = env_int("RTHIP_SCENE_LDS", t.scene_lds);
+		t.qnodes = env_int("RTHIP_QNODES", t.qnodes);
+		t.threads = env_int("RTHIP_THREADS", t.threads);
+		t.blocks_per_cu = env_int("RTHIP_BLOCKS_PER_CU", t.blocks_per_cu);
+		t.chunk = env_int("RTHIP_CHUNK", t.chunk);
+		t.trav_threshold = env_int("RTHIP_TRAV_THRESHOLD", t.trav_threshold);
+		t.inner_exit = env_int("RTHIP_INNER_EXIT", t.inner_exit);
+		t.regen_min = env_int("RTHIP_REGEN_MIN", t.regen_min);
+		t.block_order = env_int("RTHIP_BLOCK_ORDER", t.block_order);
+		t.wf_batch = env_int("RTHIP_WF_BATCH", t.wf_batch);
+		t.count = env_int("RTHIP_COUNT", t.count);
+		if (const char* v = std::getenv("RTHIP_REGION_DUMP")) t.region_dump = v;
+		return t;
+	}
+};
 }  // namespace
 
 struct rthip_ctx {
@@ -38,7 +80,7 @@ struct rthip_ctx {
 
 	bool has_scene = false, has_camera = false;
 	SceneBlob blob32, blob64;
-	int tree_depth = 0, n_nodes = 0, n_leaves = 0, n_prims = 0;
+	int tree_depth = 0, n_nodes = 0, n_leaves = 0, n_prims = 0, n_gates = 0;
 	int32_t big_leaf = 0, start = 0;  // leaf of oversized primitives tested at ray start, and the tree's entry after it
 
 	CameraFields cam{};
@@ -50,6 +92,12 @@ struct rthip_ctx {
 	uint64_t accum_words = 0;
 
 	char* d_control = nullptr;  // 1024 bytes: statistics words from +8, work-queue counters from +512 (one per 64-byte line)
+	char* static_control = nullptr;  // the same block inside this device's static scratch array (rthip_render_accumulate_noalloc)
+	char* last_control = nullptr;    // the block the last launch used: where its statistics are
+	Tuning tune;
+	BuildOptions build_opt;
+	// resident workgroups per CU by (f64, wavefront, threads, scene in LDS, quantised, dynamic LDS bytes): asked of the runtime once
+	std::map<std::tuple<bool, bool, int, bool, bool, size_t>, int> occupancy;
 	// wavefront variant: ping-pong path state, hit records and the per-bounce counter block
 	char* wf_mem = nullptr;
 	size_t wf_bytes = 0;
@@ -63,9 +111,26 @@ struct rthip_ctx {
 
 namespace {
 
-int32_t fail(rthip_ctx* c, int32_t code, const std::string& msg) {
-	if (c) c->err = msg; else g_create_error = msg;
+int32_t fail(rthip_ctx* c, int32_t code, const std::string& msg) noexcept {
+	try {
+		if (c) c->err = msg; else g_create_error = msg;
+	} catch (...) {  // no memory for the message: the status still goes out
+	}
 	return code;
+}
+// Every extern "C" body runs inside this: nothing a C++ library routine throws (bad_alloc from a
+// vector, a thread that cannot start) may unwind across the C ABI.
+template <typename F>
+int32_t guarded(rthip_ctx* c, F&& body) noexcept {
+	try {
+		return body();
+	} catch (const std::bad_alloc&) {
+		return fail(c, RTHIP_ERR_LIMIT, "out of host memory");
+	} catch (const std::exception& e) {
+		return fail(c, RTHIP_ERR_INTERNAL, e.what());
+	} catch (...) {
+		return fail(c, RTHIP_ERR_INTERNAL, "unknown exception");
+	}
 }
 #define HIP_TRY(ctx, expr)                                                                                     \
 	do {                                                                                                       \
@@ -109,27 +174,11 @@ int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const st
 	return RTHIP_OK;
 }
 
-// The host build allocates and starts threads; nothing it throws may cross the C ABI.
-bool build_scene_guarded(const rthip_object* objects, int64_t n, FlatScene* flat, std::string* err) {
-	try {
-		return build_flat_scene(objects, n, flat, err);
-	} catch (const std::exception& e) {
-		*err = std::string("scene build failed: ") + e.what();
-	} catch (...) {
-		*err = "scene build failed";
-	}
-	flat->depth = kStackMax + 1;  // reported as RTHIP_ERR_LIMIT
-	return false;
-}
-
-int env_int(const char* name, int dflt) {
-	const char* v = std::getenv(name);
-	return (v && *v) ? std::atoi(v) : dflt;
-}
 
 // Scenes up to this size are copied into LDS by every workgroup of the render kernel.
 constexpr uint32_t kLdsSceneLimit = 64 * 1024;
 constexpr int kWfMaxDepth = 4096;
+constexpr size_t kControlBytes = 1024;  // control block of a launch: statistics from +8, work-queue counters from +512
 
 struct Plan {
 	LaunchCfg cfg;
@@ -151,33 +200,46 @@ int32_t validate(rthip_ctx* c, const rthip_render_params* p) {
 	return RTHIP_OK;
 }
 
+// Resident workgroups per CU, asked of the runtime once per kernel variant and LDS size.
+int32_t blocks_per_cu(rthip_ctx* c, bool f64, bool wavefront, int threads, bool in_lds, bool quantised, size_t lds, int* out) {
+	const auto key = std::make_tuple(f64, wavefront, threads, in_lds, quantised, lds);
+	auto it = c->occupancy.find(key);
+	if (it != c->occupancy.end()) { *out = it->second; return RTHIP_OK; }
+	int b = 0;
+	if (wavefront) HIP_TRY(c, f64 ? wf_extend_blocks_per_cu_f64(threads, in_lds, lds, &b) : wf_extend_blocks_per_cu_f32(threads, in_lds, lds, &b));
+	else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, in_lds, lds, &b) : render_blocks_per_cu_f32(threads, in_lds, lds, &b, quantised));
+	c->occupancy[key] = b;
+	*out = b;
+	return RTHIP_OK;
+}
+
 int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* plan, bool wavefront = false) {
 	const bool f64 = p->precision == RTHIP_F64;
 	const SceneBlob& blob = f64 ? c->blob64 : c->blob32;
-	int lds_mode = env_int("RTHIP_SCENE_LDS", -1);
-	bool in_lds = lds_mode < 0 ? blob.lds_bytes <= kLdsSceneLimit : (lds_mode != 0 && blob.lds_bytes <= 100 * 1024);
+	const Tuning& tune = c->tune;
+	bool in_lds = tune.scene_lds < 0 ? blob.lds_bytes <= kLdsSceneLimit : (tune.scene_lds != 0 && blob.lds_bytes <= 100 * 1024);
 	plan->cfg.scene_in_lds = in_lds;
 	plan->cfg.count = count;
-	plan->cfg.quantised = !in_lds && !f64 && !wavefront && blob.qnodes_off != 0 && env_int("RTHIP_QNODES", 1) != 0;
+	plan->cfg.quantised = !in_lds && !f64 && !wavefront && blob.qnodes_off != 0 && tune.qnodes != 0;
 	// Workgroup size: the kernel is latency bound, so pick the size that keeps the most waves
 	// resident.  Every workgroup holds its own LDS copy of the scene, so larger workgroups
 	// amortise it.
-	int forced = env_int("RTHIP_THREADS", 0);
+	const int forced = tune.threads;
 	int best_waves = -1, bpc = 0;
 	for (int threads : {256, 512, 1024}) {
 		if (forced && threads != forced) continue;
 		if (threads == 1024 && (wavefront || forced != 1024)) continue;  // 32 waves per CU at 64 VGPRs measured no faster than 24 at 80: on request only
 		size_t lds = (size_t)c->tree_depth * threads * 4 + (in_lds ? blob.lds_bytes : 0);
 		int b = 0;
-		if (wavefront) HIP_TRY(c, f64 ? wf_extend_blocks_per_cu_f64(threads, in_lds, lds, &b) : wf_extend_blocks_per_cu_f32(threads, in_lds, lds, &b));
-		else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, in_lds, lds, &b) : render_blocks_per_cu_f32(threads, in_lds, lds, &b, plan->cfg.quantised));
+		int32_t rc = blocks_per_cu(c, f64, wavefront, threads, in_lds, plan->cfg.quantised, lds, &b);
+		if (rc != RTHIP_OK) return rc;
 		if (b * threads / 64 > best_waves) {
 			best_waves = b * threads / 64; bpc = b;
 			plan->cfg.threads = threads; plan->cfg.dyn_lds = lds;
 		}
 	}
 	if (bpc < 1) return fail(c, RTHIP_ERR_LIMIT, "render kernel does not fit on a CU");
-	int cap = env_int("RTHIP_BLOCKS_PER_CU", 0);
+	const int cap = tune.blocks_per_cu;
 	if (cap > 0) bpc = std::min(bpc, cap);
 	uint64_t n_tiles = (uint64_t)c->tiles_x * c->tiles_y;
 	uint64_t my_tiles = n_tiles > (uint64_t)p->part_index ? (n_tiles - p->part_index + p->part_count - 1) / p->part_count : 0;
@@ -189,12 +251,10 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// Very short paths (a few objects under an open sky: 1.3 rays per path, two node visits each)
 	// spend a third of their time on accumulation atomics, and those run faster when a tile's
 	// samples follow one another: 32 samples per item gave 52 instead of 38 Gpaths/s on the
-	// three-object scene at any spp.  Recognised by the tree (nothing below the root) or by the
-	// rate of the last launch measured on this context.
-	const bool short_paths = c->n_nodes <= 1 || (c->stats.paths >= (1u << 20) && c->stats.kernel_ms > 0.f &&
-	                                             (double)c->stats.paths / c->stats.kernel_ms > 25e6);
-	if (short_paths) auto_chunk = 32;
-	uint32_t chunk = (uint32_t)std::max(1, env_int("RTHIP_CHUNK", (int)auto_chunk));
+	// three-object scene at any spp.  Recognised by the tree alone (nothing below the root), so
+	// that a launch does not depend on the launches before it.
+	if (c->n_nodes <= 1) auto_chunk = 32;
+	uint32_t chunk = (uint32_t)std::max(1, tune.chunk > 0 ? tune.chunk : (int)auto_chunk);
 	chunk = std::min<uint32_t>(chunk, std::max<uint32_t>(1u, p->spp_count));
 	uint32_t n_chunks = (p->spp_count + chunk - 1) / chunk;
 	uint64_t n_items = my_tiles * n_chunks;
@@ -209,12 +269,13 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	plan->cfg.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc * c->num_cu, want_blocks));
 	// Leave the traversal loop for shading / regeneration once this few lanes are still in it.
 	// Measured optimum: 12-16 with the scene in LDS, about 36 when every node is a trip to L1 or L2.
-	plan->threshold = env_int("RTHIP_TRAV_THRESHOLD", in_lds ? 14 : 36);
+	plan->threshold = tune.trav_threshold >= 0 ? tune.trav_threshold : (in_lds ? 14 : 36);
 	return RTHIP_OK;
 }
 
 template <typename Real>
-int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, unsigned long long* accum, Real* samples_out) {
+int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, unsigned long long* accum, Real* samples_out, char* control = nullptr) {
+	if (!control) control = c->d_control;
 	Plan plan;
 	int32_t rc = make_plan(c, p, count, &plan);
 	if (rc != RTHIP_OK) return rc;
@@ -231,17 +292,19 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.spp_begin = p->spp_begin; a.spp_count = p->spp_count; a.max_depth = p->max_depth; a.seed = p->seed;
 	a.sky_mode = p->sky_mode; a.part_index = p->part_index; a.part_count = p->part_count;
 	a.n_items = plan.n_items; a.chunk = plan.chunk; a.n_chunks = plan.n_chunks; a.trav_threshold = plan.threshold;
-	a.inner_exit = env_int("RTHIP_INNER_EXIT", plan.cfg.scene_in_lds ? 5 : 8);
-	a.regen_min = std::max(1, std::min(64, env_int("RTHIP_REGEN_MIN", 16)));
-	a.block_order = (uint32_t)std::max(0, std::min(1024, env_int("RTHIP_BLOCK_ORDER", 32)));
+	// sixteenths of the lanes that entered a round; beyond 16 no lane would ever take a step
+	a.inner_exit = std::max(0, std::min(16, c->tune.inner_exit >= 0 ? c->tune.inner_exit : (plan.cfg.scene_in_lds ? 5 : 8)));
+	a.regen_min = std::max(1, std::min(64, c->tune.regen_min));
+	a.block_order = (uint32_t)std::max(0, std::min(1024, c->tune.block_order));
 	a.accum = accum; a.samples_out = samples_out;
-	a.queue = reinterpret_cast<uint32_t*>(c->d_control + 512);
-	a.stats = reinterpret_cast<unsigned long long*>(c->d_control + 8);
-	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 1024, c->stream));
+	a.queue = reinterpret_cast<uint32_t*>(control + 512);
+	a.stats = reinterpret_cast<unsigned long long*>(control + 8);
+	HIP_TRY(c, hipMemsetAsync(control, 0, kControlBytes, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
 	if (plan.n_items > 0 && p->spp_count > 0) HIP_TRY(c, launch_render(a, plan.cfg, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
 	c->launch_pending = true;
+	c->last_control = control;
 	c->last_in_lds = plan.cfg.scene_in_lds;
 	return RTHIP_OK;
 }
@@ -255,7 +318,7 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 	const SceneBlob& blob = std::is_same<Real, double>::value ? c->blob64 : c->blob32;
 	const uint64_t per_item = (uint64_t)kTilePixels * plan.chunk;
 	const uint64_t total = (uint64_t)plan.n_items * per_item;
-	uint64_t batch = (uint64_t)std::max(1, env_int("RTHIP_WF_BATCH", 64 << 20));
+	uint64_t batch = (uint64_t)std::max(1, c->tune.wf_batch);
 	batch = std::min<uint64_t>(std::max<uint64_t>(batch, per_item), std::max<uint64_t>(total, 1));
 	if (batch > 0xFFFFFF00ull) batch = 0xFFFFFF00ull;
 	// carve the state memory: two states (3 quads + meta + slot) and the hit records
@@ -294,7 +357,7 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 	const int depth = std::max(0, p->max_depth);
 	uint32_t* n = c->wf_counters;
 	uint32_t* fetch = c->wf_counters + kWfMaxDepth + 1;
-	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, 1024, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->d_control, 0, kControlBytes, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
 	for (uint64_t begin = 0; begin < total && p->spp_count > 0; begin += batch) {
 		HIP_TRY(c, hipMemsetAsync(c->wf_counters, 0, (2 * kWfMaxDepth + 2) * sizeof(uint32_t), c->stream));
@@ -317,6 +380,7 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 	}
 	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
 	c->launch_pending = true;
+	c->last_control = c->d_control;
 	c->last_in_lds = plan.cfg.scene_in_lds;
 	return RTHIP_OK;
 }
@@ -325,10 +389,10 @@ int32_t collect_stats(rthip_ctx* c) {
 	if (!c->launch_pending) return RTHIP_OK;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	unsigned long long s[5 + 2 * kRegCount];
-	HIP_TRY(c, hipMemcpy(s, c->d_control + 8, sizeof(s), hipMemcpyDeviceToHost));
-	if (const char* dump = std::getenv("RTHIP_REGION_DUMP")) {  // instrumented runs: lane utilisation per code region
+	HIP_TRY(c, hipMemcpy(s, (c->last_control ? c->last_control : c->d_control) + 8, sizeof(s), hipMemcpyDeviceToHost));
+	if (!c->tune.region_dump.empty() && c->tune.count) {  // instrumented runs: lane utilisation per code region
 		static const char* names[kRegCount] = {"inner", "sphere", "cube", "leaf", "shade", "sky", "lambert", "metal", "glass", "start", "trav_round"};
-		if (FILE* f = std::fopen(dump, "a")) {
+		if (FILE* f = std::fopen(c->tune.region_dump.c_str(), "a")) {
 			for (int k = 0; k < kRegCount; k++)
 				std::fprintf(f, "%s lane_iters %llu wave_iters %llu util %.3f\n", names[k], s[5 + k], s[5 + kRegCount + k],
 				             s[5 + kRegCount + k] ? (double)s[5 + k] / (64.0 * (double)s[5 + kRegCount + k]) : 0.0);
@@ -365,135 +429,225 @@ int32_t ensure_accum(rthip_ctx* c) {
 extern "C" {
 
 int32_t rthip_create(int32_t device, rthip_ctx** out) {
-	if (!out) return fail(nullptr, RTHIP_ERR_INVALID, "out is NULL");
-	*out = nullptr;
-	int n = 0;
-	hipError_t e = hipGetDeviceCount(&n);
-	if (e != hipSuccess || n < 1) return fail(nullptr, RTHIP_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
-	if (device < 0 || device >= n) return fail(nullptr, RTHIP_ERR_INVALID, "device ordinal out of range");
-	rthip_ctx* c = new rthip_ctx();
-	c->device = device;
-	auto bail = [&](const char* what, hipError_t err) {
-		std::string msg = std::string(what) + ": " + hipGetErrorString(err);
-		rthip_destroy(c);
-		return fail(nullptr, RTHIP_ERR_HIP, msg);
-	};
-	if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
-	hipDeviceProp_t prop;
-	if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
-	c->num_cu = prop.multiProcessorCount;
-	if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-	c->stream = c->own_stream;
-	if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
-	if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-	if ((e = hipMalloc(&c->d_control, 1024)) != hipSuccess) return bail("hipMalloc", e);
-	*out = c;
-	return RTHIP_OK;
+	return guarded(nullptr, [&]() -> int32_t {
+		if (!out) return fail(nullptr, RTHIP_ERR_INVALID, "out is NULL");
+		*out = nullptr;
+		int n = 0;
+		hipError_t e = hipGetDeviceCount(&n);
+		if (e != hipSuccess || n < 1) return fail(nullptr, RTHIP_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+		if (device < 0 || device >= n) return fail(nullptr, RTHIP_ERR_INVALID, "device ordinal out of range");
+		rthip_ctx* c = new rthip_ctx();
+		c->device = device;
+		auto bail = [&](const char* what, hipError_t err) {
+			std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+			rthip_destroy(c);
+			return fail(nullptr, RTHIP_ERR_HIP, msg);
+		};
+		try {
+			c->tune = Tuning::from_env();
+			c->build_opt = BuildOptions::from_env();
+		} catch (...) {
+			rthip_destroy(c);
+			throw;
+		}
+		if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+		hipDeviceProp_t prop;
+		if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+		c->num_cu = prop.multiProcessorCount;
+		if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+		c->stream = c->own_stream;
+		if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+		if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+		if ((e = hipMalloc(&c->d_control, kControlBytes)) != hipSuccess) return bail("hipMalloc", e);
+		// this device's copy of the static scratch array (the allocation-free entry point launches on it)
+		void* scratch = nullptr;
+		if ((e = static_scratch_for_device(device, &scratch)) != hipSuccess) return bail("hipGetSymbolAddress(static scratch)", e);
+		c->static_control = static_cast<char*>(scratch);
+		*out = c;
+		return RTHIP_OK;
+	});
 }
 
 void rthip_destroy(rthip_ctx* c) {
 	if (!c) return;
-	(void)hipSetDevice(c->device);
-	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	if (c->blob32.dev) (void)hipFree(c->blob32.dev);
-	if (c->blob64.dev) (void)hipFree(c->blob64.dev);
-	if (c->own_accum) (void)hipFree(c->own_accum);
-	if (c->d_control) (void)hipFree(c->d_control);
-	if (c->wf_mem) (void)hipFree(c->wf_mem);
-	if (c->readback) (void)hipFree(c->readback);
-	if (c->wf_counters) (void)hipFree(c->wf_counters);
-	if (c->ev0) (void)hipEventDestroy(c->ev0);
-	if (c->ev1) (void)hipEventDestroy(c->ev1);
-	if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-	delete c;
+	try {
+		(void)hipSetDevice(c->device);
+		if (c->stream) (void)hipStreamSynchronize(c->stream);
+		if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
+		if (c->blob32.dev) (void)hipFree(c->blob32.dev);
+		if (c->blob64.dev) (void)hipFree(c->blob64.dev);
+		if (c->own_accum) (void)hipFree(c->own_accum);
+		if (c->d_control) (void)hipFree(c->d_control);
+		if (c->wf_mem) (void)hipFree(c->wf_mem);
+		if (c->readback) (void)hipFree(c->readback);
+		if (c->wf_counters) (void)hipFree(c->wf_counters);
+		if (c->ev0) (void)hipEventDestroy(c->ev0);
+		if (c->ev1) (void)hipEventDestroy(c->ev1);
+		if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+		delete c;
+	} catch (...) {
+	}
 }
 
 const char* rthip_last_error(const rthip_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int32_t rthip_set_stream(rthip_ctx* c, void* hip_stream) {
 	if (!c) return RTHIP_ERR_INVALID;
-	HIP_TRY(c, hipSetDevice(c->device));
-	int32_t rc = collect_stats(c);
-	if (rc != RTHIP_OK) return rc;
-	c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		HIP_TRY(c, hipSetDevice(c->device));
+		// Everything queued on the old stream (renders, but also the zero-fills of rthip_camera_set and
+		// rthip_reset_accumulation) must be done before work on the new stream may touch the same
+		// buffers: the two streams are not ordered against each other.
+		int32_t rc = collect_stats(c);
+		if (rc != RTHIP_OK) return rc;
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+		return RTHIP_OK;
+	});
+}
+
+int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
+	if (!c) return RTHIP_ERR_INVALID;
+	return guarded(c, [&]() -> int32_t {
+		if (!name) return fail(c, RTHIP_ERR_INVALID, "option name is NULL");
+		if (!(value == value)) return fail(c, RTHIP_ERR_INVALID, "option value is NaN");
+		const std::string k(name);
+		const int iv = (int)value;
+		Tuning& t = c->tune;
+		BuildOptions& b = c->build_opt;
+		if (k == "scene_lds") t.scene_lds = iv;
+		else if (k == "qnodes") t.qnodes = iv;
+		else if (k == "threads") t.threads = iv;
+		else if (k == "blocks_per_cu") t.blocks_per_cu = iv;
+		else if (k == "chunk") t.chunk = iv;
+		else if (k == "trav_threshold") t.trav_threshold = iv;
+		else if (k == "inner_exit") t.inner_exit = iv;
+		else if (k == "regen_min") t.regen_min = iv;
+		else if (k == "block_order") t.block_order = iv;
+		else if (k == "wf_batch") t.wf_batch = iv;
+		else if (k == "count") t.count = iv;
+		else if (k == "tree_ref") b.tree_ref = iv != 0;
+		else if (k == "sah_leaf") b.sah_leaf = iv;
+		else if (k == "sah_cprim") b.sah_cprim = value;
+		else if (k == "sah_sweep") b.sah_sweep = iv;
+		else if (k == "big_leaf_min") b.big_leaf_min = iv;
+		else if (k == "no_big_leaf") b.no_big_leaf = iv != 0;
+		else if (k == "no_qnodes") b.no_qnodes = iv != 0;
+		else if (k == "build_threads") b.threads = iv != 1;
+		else if (k == "tie_reverse") b.tie_reverse = iv != 0;
+		else return fail(c, RTHIP_ERR_INVALID, "unknown option '" + k + "'");
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n) {
 	if (!c) return RTHIP_ERR_INVALID;
-	if (n < 0 || (n > 0 && !objects)) return fail(c, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
-	if (n == 0) return fail(c, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
-	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	FlatScene flat;
-	std::string err;
-	if (!build_scene_guarded(objects, n, &flat, &err)) return fail(c, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
-	c->has_scene = false;
-	int32_t rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32, &flat.qnodes, &flat.qframe);
-	if (rc != RTHIP_OK) return rc;
-	rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
-	if (rc != RTHIP_OK) return rc;
-	c->big_leaf = flat.big_leaf; c->start = flat.start;
-	c->tree_depth = flat.depth; c->n_nodes = (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)flat.prims32.size();
-	c->stats.n_nodes = c->n_nodes; c->stats.n_leaves = c->n_leaves; c->stats.n_prims = c->n_prims; c->stats.tree_depth = c->tree_depth;
-	c->has_scene = true;
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		if (n < 0 || (n > 0 && !objects)) return fail(c, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
+		if (n == 0) return fail(c, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
+		HIP_TRY(c, hipSetDevice(c->device));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		FlatScene flat;
+		std::string err;
+		if (!build_flat_scene(objects, n, &flat, &err, c->build_opt)) return fail(c, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+		c->has_scene = false;
+		int32_t rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32, &flat.qnodes, &flat.qframe);
+		if (rc != RTHIP_OK) return rc;
+		rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
+		if (rc != RTHIP_OK) return rc;
+		c->big_leaf = flat.big_leaf; c->start = flat.start;
+		c->tree_depth = flat.depth; c->n_nodes = (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)flat.prims32.size();
+		c->n_gates = (int)flat.gates32.size();
+		c->stats.n_nodes = c->n_nodes; c->stats.n_leaves = c->n_leaves; c->stats.n_prims = c->n_prims; c->stats.tree_depth = c->tree_depth;
+		c->stats.n_gates = c->n_gates;
+		c->has_scene = true;
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_camera_set(rthip_ctx* c, const rthip_camera_desc* d) {
 	if (!c) return RTHIP_ERR_INVALID;
-	if (!d) return fail(c, RTHIP_ERR_INVALID, "camera is NULL");
-	if (d->width < 1 || d->height < 1 || (int64_t)d->width * d->height > (1ll << 28)) return fail(c, RTHIP_ERR_INVALID, "image size out of range");
-	if (!(d->focus_dist == d->focus_dist) || !(d->fov == d->fov)) return fail(c, RTHIP_ERR_INVALID, "camera has NaN fields");
-	HIP_TRY(c, hipSetDevice(c->device));
-	bool resized = !c->has_camera || d->width != c->cam.width || d->height != c->cam.height;
-	c->cam = camera_new(*d);
-	c->tiles_x = (d->width + kTile - 1) / kTile;
-	c->tiles_y = (d->height + kTile - 1) / kTile;
-	c->has_camera = true;
-	if (resized) {
-		HIP_TRY(c, hipStreamSynchronize(c->stream));
-		if (c->accum && c->accum != c->own_accum) { c->accum = nullptr; c->accum_words = 0; }  // caller's buffer no longer fits
-		int32_t rc = ensure_accum(c);
-		if (rc != RTHIP_OK) return rc;
-		HIP_TRY(c, hipMemsetAsync(c->accum, 0, c->accum_words * 8, c->stream));
-	}
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		if (!d) return fail(c, RTHIP_ERR_INVALID, "camera is NULL");
+		if (d->width < 1 || d->height < 1 || (int64_t)d->width * d->height > (1ll << 28)) return fail(c, RTHIP_ERR_INVALID, "image size out of range");
+		if (!(d->focus_dist == d->focus_dist) || !(d->fov == d->fov)) return fail(c, RTHIP_ERR_INVALID, "camera has NaN fields");
+		HIP_TRY(c, hipSetDevice(c->device));
+		bool resized = !c->has_camera || d->width != c->cam.width || d->height != c->cam.height;
+		c->cam = camera_new(*d);
+		c->tiles_x = (d->width + kTile - 1) / kTile;
+		c->tiles_y = (d->height + kTile - 1) / kTile;
+		c->has_camera = true;
+		if (resized) {
+			HIP_TRY(c, hipStreamSynchronize(c->stream));
+			if (c->accum && c->accum != c->own_accum) { c->accum = nullptr; c->accum_words = 0; }  // caller's buffer no longer fits
+			int32_t rc = ensure_accum(c);
+			if (rc != RTHIP_OK) return rc;
+			HIP_TRY(c, hipMemsetAsync(c->accum, 0, c->accum_words * 8, c->stream));
+		}
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_camera_fields(const rthip_camera_desc* d, double out[19]) {
-	if (!d || !out) return fail(nullptr, RTHIP_ERR_INVALID, "camera or out is NULL");
-	if (d->width < 1 || d->height < 1) return fail(nullptr, RTHIP_ERR_INVALID, "image size out of range");
-	CameraFields f = camera_new(*d);
-	const double* src[6] = {f.origin, f.pixel00, f.delta_x, f.delta_y, f.disk_x, f.disk_y};
-	for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) out[3 * i + k] = src[i][k];
-	out[18] = f.defocus_angle;
-	return RTHIP_OK;
+	return guarded(nullptr, [&]() -> int32_t {
+		if (!d || !out) return fail(nullptr, RTHIP_ERR_INVALID, "camera or out is NULL");
+		if (d->width < 1 || d->height < 1) return fail(nullptr, RTHIP_ERR_INVALID, "image size out of range");
+		CameraFields f = camera_new(*d);
+		const double* src[6] = {f.origin, f.pixel00, f.delta_x, f.delta_y, f.disk_x, f.disk_y};
+		for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) out[3 * i + k] = src[i][k];
+		out[18] = f.defocus_angle;
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_render_accumulate_async(rthip_ctx* c, const rthip_render_params* p) {
-	int32_t rc = validate(c, p);
-	if (rc != RTHIP_OK) return rc;
-	HIP_TRY(c, hipSetDevice(c->device));
-	// No wait for the previous launch: the control block (work counters, statistics) is cleared and
-	// used in stream order, so launches queue up back to back; statistics are those of the last one.
-	if ((rc = ensure_accum(c)) != RTHIP_OK) return rc;
-	bool count = env_int("RTHIP_COUNT", 0) != 0;
-	if (p->variant == RTHIP_WAVEFRONT) {
-		if (p->precision == RTHIP_F64) return enqueue_wavefront<double>(c, p, c->accum, nullptr);
-		return enqueue_wavefront<float>(c, p, c->accum, nullptr);
-	}
-	if (p->precision == RTHIP_F64) return enqueue_render<double>(c, p, count, c->accum, nullptr);
-	return enqueue_render<float>(c, p, count, c->accum, nullptr);
+	if (!c) return RTHIP_ERR_INVALID;
+	return guarded(c, [&]() -> int32_t {
+		int32_t rc = validate(c, p);
+		if (rc != RTHIP_OK) return rc;
+		HIP_TRY(c, hipSetDevice(c->device));
+		// No wait for the previous launch: the control block (work counters, statistics) is cleared and
+		// used in stream order, so launches queue up back to back; statistics are those of the last one.
+		if ((rc = ensure_accum(c)) != RTHIP_OK) return rc;
+		const bool count = c->tune.count != 0;
+		if (p->variant == RTHIP_WAVEFRONT) {
+			if (p->precision == RTHIP_F64) return enqueue_wavefront<double>(c, p, c->accum, nullptr);
+			return enqueue_wavefront<float>(c, p, c->accum, nullptr);
+		}
+		if (p->precision == RTHIP_F64) return enqueue_render<double>(c, p, count, c->accum, nullptr);
+		return enqueue_render<float>(c, p, count, c->accum, nullptr);
+	});
+}
+
+int32_t rthip_render_accumulate_noalloc(rthip_ctx* c, const rthip_render_params* p) {
+	if (!c) return RTHIP_ERR_INVALID;
+	return guarded(c, [&]() -> int32_t {
+		int32_t rc = validate(c, p);
+		if (rc != RTHIP_OK) return rc;
+		if (p->variant != RTHIP_MEGAKERNEL)
+			return fail(c, RTHIP_ERR_LIMIT, "rthip_render_accumulate_noalloc: the wavefront variant keeps gigabytes of path state in allocated memory; "
+			                                "only RTHIP_MEGAKERNEL runs without allocation");
+		static_assert(kControlBytes <= kStaticScratchBytes, "the control block must fit the static scratch array");
+		if (!c->static_control) return fail(c, RTHIP_ERR_STATE, "rthip_render_accumulate_noalloc: no static scratch on this device");
+		const uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
+		if (!c->accum || c->accum_words != words)
+			return fail(c, RTHIP_ERR_STATE, "rthip_render_accumulate_noalloc: no accumulation buffer of the image's size is set (it will not allocate one)");
+		HIP_TRY(c, hipSetDevice(c->device));
+		// the kernels take the scratch pointer as they take the allocated control block in rthip_render_accumulate_async
+		if (p->precision == RTHIP_F64) return enqueue_render<double>(c, p, false, c->accum, nullptr, c->static_control);
+		return enqueue_render<float>(c, p, false, c->accum, nullptr, c->static_control);
+	});
 }
 
 int32_t rthip_synchronize(rthip_ctx* c) {
 	if (!c) return RTHIP_ERR_INVALID;
-	HIP_TRY(c, hipSetDevice(c->device));
-	int32_t rc = collect_stats(c);
-	if (rc != RTHIP_OK) return rc;
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		HIP_TRY(c, hipSetDevice(c->device));
+		int32_t rc = collect_stats(c);
+		if (rc != RTHIP_OK) return rc;
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_render_accumulate(rthip_ctx* c, const rthip_render_params* p) {
@@ -504,49 +658,57 @@ int32_t rthip_render_accumulate(rthip_ctx* c, const rthip_render_params* p) {
 
 int32_t rthip_reset_accumulation(rthip_ctx* c) {
 	if (!c) return RTHIP_ERR_INVALID;
-	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
-	HIP_TRY(c, hipSetDevice(c->device));
-	int32_t rc = ensure_accum(c);
-	if (rc != RTHIP_OK) return rc;
-	HIP_TRY(c, hipMemsetAsync(c->accum, 0, c->accum_words * 8, c->stream));
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+		HIP_TRY(c, hipSetDevice(c->device));
+		int32_t rc = ensure_accum(c);
+		if (rc != RTHIP_OK) return rc;
+		HIP_TRY(c, hipMemsetAsync(c->accum, 0, c->accum_words * 8, c->stream));
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_accum_buffer(rthip_ctx* c, void** device_ptr, uint64_t* n_words) {
 	if (!c || !device_ptr || !n_words) return RTHIP_ERR_INVALID;
-	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
-	HIP_TRY(c, hipSetDevice(c->device));
-	int32_t rc = ensure_accum(c);
-	if (rc != RTHIP_OK) return rc;
-	*device_ptr = c->accum; *n_words = c->accum_words;
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+		HIP_TRY(c, hipSetDevice(c->device));
+		int32_t rc = ensure_accum(c);
+		if (rc != RTHIP_OK) return rc;
+		*device_ptr = c->accum; *n_words = c->accum_words;
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_set_accum_buffer(rthip_ctx* c, void* device_ptr, uint64_t n_words) {
 	if (!c) return RTHIP_ERR_INVALID;
-	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
-	HIP_TRY(c, hipSetDevice(c->device));
-	// No wait here: launches already queued carry the pointer they were given, and later calls
-	// are ordered behind them on the stream.
-	if (!device_ptr) { c->accum = nullptr; c->accum_words = 0; return ensure_accum(c); }
-	uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
-	if (n_words != words) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must hold tiles_x*tiles_y*192 words");
-	if (reinterpret_cast<uintptr_t>(device_ptr) % 8) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must be 8-byte aligned");
-	c->accum = static_cast<unsigned long long*>(device_ptr); c->accum_words = words;
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+		HIP_TRY(c, hipSetDevice(c->device));
+		// No wait here: launches already queued carry the pointer they were given, and later calls
+		// are ordered behind them on the stream.
+		if (!device_ptr) { c->accum = nullptr; c->accum_words = 0; return ensure_accum(c); }
+		uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
+		if (n_words != words) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must hold tiles_x*tiles_y*192 words");
+		if (reinterpret_cast<uintptr_t>(device_ptr) % 8) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer must be 8-byte aligned");
+		c->accum = static_cast<unsigned long long*>(device_ptr); c->accum_words = words;
+		return RTHIP_OK;
+	});
 }
 
 static int32_t accum_copy(rthip_ctx* c, void* host, uint64_t n_words, bool to_host) {
 	if (!c || !host) return RTHIP_ERR_INVALID;
-	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
-	HIP_TRY(c, hipSetDevice(c->device));
-	int32_t rc = ensure_accum(c);
-	if (rc != RTHIP_OK) return rc;
-	if (n_words != c->accum_words) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer holds tiles_x*tiles_y*192 words");
-	if (to_host) HIP_TRY(c, hipMemcpyAsync(host, c->accum, n_words * 8, hipMemcpyDeviceToHost, c->stream));
-	else HIP_TRY(c, hipMemcpyAsync(c->accum, host, n_words * 8, hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+		HIP_TRY(c, hipSetDevice(c->device));
+		int32_t rc = ensure_accum(c);
+		if (rc != RTHIP_OK) return rc;
+		if (n_words != c->accum_words) return fail(c, RTHIP_ERR_INVALID, "accumulation buffer holds tiles_x*tiles_y*192 words");
+		if (to_host) HIP_TRY(c, hipMemcpyAsync(host, c->accum, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+		else HIP_TRY(c, hipMemcpyAsync(c->accum, host, n_words * 8, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		return RTHIP_OK;
+	});
 }
 int32_t rthip_accum_download(rthip_ctx* c, uint64_t* words, uint64_t n_words) { return accum_copy(c, words, n_words, true); }
 int32_t rthip_accum_upload(rthip_ctx* c, const uint64_t* words, uint64_t n_words) { return accum_copy(c, const_cast<uint64_t*>(words), n_words, false); }
@@ -563,34 +725,38 @@ static int32_t ensure_readback(rthip_ctx* c, size_t bytes) {
 
 int32_t rthip_read_accum(rthip_ctx* c, double* rgb) {
 	if (!c || !rgb) return RTHIP_ERR_INVALID;
-	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
-	HIP_TRY(c, hipSetDevice(c->device));
-	int32_t rc = ensure_accum(c);
-	if (rc != RTHIP_OK) return rc;
-	size_t n = (size_t)c->cam.width * c->cam.height * 3;
-	rc = ensure_readback(c, n * sizeof(double));
-	if (rc != RTHIP_OK) return rc;
-	double* d = static_cast<double*>(c->readback);
-	HIP_TRY(c, launch_unpack(c->accum, d, c->cam.width, c->cam.height, c->tiles_x, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(rgb, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+		HIP_TRY(c, hipSetDevice(c->device));
+		int32_t rc = ensure_accum(c);
+		if (rc != RTHIP_OK) return rc;
+		size_t n = (size_t)c->cam.width * c->cam.height * 3;
+		rc = ensure_readback(c, n * sizeof(double));
+		if (rc != RTHIP_OK) return rc;
+		double* d = static_cast<double*>(c->readback);
+		HIP_TRY(c, launch_unpack(c->accum, d, c->cam.width, c->cam.height, c->tiles_x, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(rgb, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		return RTHIP_OK;
+	});
 }
 
 static int32_t read_quantized(rthip_ctx* c, uint32_t spp_total, void* out, int xrgb) {
 	if (!c || !out) return RTHIP_ERR_INVALID;
-	if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
-	if (spp_total == 0) return fail(c, RTHIP_ERR_INVALID, "spp_total must be positive");
-	HIP_TRY(c, hipSetDevice(c->device));
-	int32_t rc = ensure_accum(c);
-	if (rc != RTHIP_OK) return rc;
-	size_t bytes = (size_t)c->cam.width * c->cam.height * (xrgb ? 4 : 3);
-	rc = ensure_readback(c, bytes);
-	if (rc != RTHIP_OK) return rc;
-	HIP_TRY(c, launch_finalize(c->accum, c->readback, c->cam.width, c->cam.height, c->tiles_x, spp_total, xrgb, c->stream));
-	HIP_TRY(c, hipMemcpyAsync(out, c->readback, bytes, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+		if (spp_total == 0) return fail(c, RTHIP_ERR_INVALID, "spp_total must be positive");
+		HIP_TRY(c, hipSetDevice(c->device));
+		int32_t rc = ensure_accum(c);
+		if (rc != RTHIP_OK) return rc;
+		size_t bytes = (size_t)c->cam.width * c->cam.height * (xrgb ? 4 : 3);
+		rc = ensure_readback(c, bytes);
+		if (rc != RTHIP_OK) return rc;
+		HIP_TRY(c, launch_finalize(c->accum, c->readback, c->cam.width, c->cam.height, c->tiles_x, spp_total, xrgb, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(out, c->readback, bytes, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		return RTHIP_OK;
+	});
 }
 int32_t rthip_read_rgb8(rthip_ctx* c, uint32_t spp_total, uint8_t* rgb) { return read_quantized(c, spp_total, rgb, 0); }
 int32_t rthip_read_xrgb32(rthip_ctx* c, uint32_t spp_total, uint32_t* xrgb) { return read_quantized(c, spp_total, xrgb, 1); }
@@ -598,134 +764,167 @@ int32_t rthip_read_xrgb32(rthip_ctx* c, uint32_t spp_total, uint32_t* xrgb) { re
 int32_t rthip_trace_primary(rthip_ctx* c, int32_t precision, int32_t jitter, uint32_t seed, uint32_t sample, int32_t* id, double* t,
                             double* normal, uint8_t* front_face) {
 	if (!c) return RTHIP_ERR_INVALID;
-	if (!id || !t || !normal || !front_face) return fail(c, RTHIP_ERR_INVALID, "output pointer is NULL");
-	if (!c->has_scene || !c->has_camera) return fail(c, RTHIP_ERR_STATE, "upload a scene and set a camera first");
-	if (precision != RTHIP_F32 && precision != RTHIP_F64) return fail(c, RTHIP_ERR_INVALID, "precision must be RTHIP_F32 or RTHIP_F64");
-	HIP_TRY(c, hipSetDevice(c->device));
-	size_t n = (size_t)c->cam.width * c->cam.height;
-	char* d = nullptr;
-	size_t off_t = align_up(n * 4, 64), off_n = off_t + align_up(n * 8, 64), off_f = off_n + align_up(n * 24, 64), total = off_f + align_up(n, 64);
-	HIP_TRY(c, hipMalloc(&d, total));
-	size_t lds = (size_t)c->tree_depth * kProbeBlock * 4;
-	hipError_t e;
-	if (precision == RTHIP_F64) {
-		ProbeArgs<double> a;
-		std::memset(&a, 0, sizeof(a));
-		a.scene = c->blob64.dev; a.prims_off = c->blob64.prims_off; a.mats_off = c->blob64.mats_off; a.gates_off = c->blob64.gates_off;
-		a.scene_bytes = c->blob64.bytes;
-		a.stack_entries = c->tree_depth; fill_camera<double>(c->cam, &a.cam);
-		a.width = c->cam.width; a.height = c->cam.height; a.seed = seed; a.sample = sample; a.jitter = jitter;
-		a.id = reinterpret_cast<int32_t*>(d); a.t = reinterpret_cast<double*>(d + off_t); a.normal = reinterpret_cast<double*>(d + off_n);
-		a.front = reinterpret_cast<uint8_t*>(d + off_f);
-		e = launch_probe(a, lds, c->stream);
-	} else {
-		ProbeArgs<float> a;
-		std::memset(&a, 0, sizeof(a));
-		a.scene = c->blob32.dev; a.prims_off = c->blob32.prims_off; a.mats_off = c->blob32.mats_off; a.gates_off = c->blob32.gates_off;
-		a.scene_bytes = c->blob32.bytes;
-		a.stack_entries = c->tree_depth; fill_camera<float>(c->cam, &a.cam);
-		a.width = c->cam.width; a.height = c->cam.height; a.seed = seed; a.sample = sample; a.jitter = jitter;
-		a.id = reinterpret_cast<int32_t*>(d); a.t = reinterpret_cast<double*>(d + off_t); a.normal = reinterpret_cast<double*>(d + off_n);
-		a.front = reinterpret_cast<uint8_t*>(d + off_f);
-		e = launch_probe(a, lds, c->stream);
-	}
-	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	if (e == hipSuccess) e = hipMemcpy(id, d, n * 4, hipMemcpyDeviceToHost);
-	if (e == hipSuccess) e = hipMemcpy(t, d + off_t, n * 8, hipMemcpyDeviceToHost);
-	if (e == hipSuccess) e = hipMemcpy(normal, d + off_n, n * 24, hipMemcpyDeviceToHost);
-	if (e == hipSuccess) e = hipMemcpy(front_face, d + off_f, n, hipMemcpyDeviceToHost);
-	(void)hipFree(d);
-	HIP_TRY(c, e);
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		if (!id || !t || !normal || !front_face) return fail(c, RTHIP_ERR_INVALID, "output pointer is NULL");
+		if (!c->has_scene || !c->has_camera) return fail(c, RTHIP_ERR_STATE, "upload a scene and set a camera first");
+		if (precision != RTHIP_F32 && precision != RTHIP_F64 && precision != RTHIP_F32_RAW) return fail(c, RTHIP_ERR_INVALID, "precision must be RTHIP_F32, RTHIP_F64 or RTHIP_F32_RAW");
+		HIP_TRY(c, hipSetDevice(c->device));
+		size_t n = (size_t)c->cam.width * c->cam.height;
+		char* d = nullptr;
+		size_t off_t = align_up(n * 4, 64), off_n = off_t + align_up(n * 8, 64), off_f = off_n + align_up(n * 24, 64), total = off_f + align_up(n, 64);
+		HIP_TRY(c, hipMalloc(&d, total));
+		size_t lds = (size_t)c->tree_depth * kProbeBlock * 4;
+		hipError_t e;
+		if (precision == RTHIP_F64) {
+			ProbeArgs<double> a;
+			std::memset(&a, 0, sizeof(a));
+			a.scene = c->blob64.dev; a.prims_off = c->blob64.prims_off; a.mats_off = c->blob64.mats_off; a.gates_off = c->blob64.gates_off;
+			a.scene_bytes = c->blob64.bytes;
+			a.stack_entries = c->tree_depth; fill_camera<double>(c->cam, &a.cam);
+			a.width = c->cam.width; a.height = c->cam.height; a.seed = seed; a.sample = sample; a.jitter = jitter;
+			a.id = reinterpret_cast<int32_t*>(d); a.t = reinterpret_cast<double*>(d + off_t); a.normal = reinterpret_cast<double*>(d + off_n);
+			a.front = reinterpret_cast<uint8_t*>(d + off_f);
+			e = launch_probe(a, lds, c->stream);
+		} else {
+			ProbeArgs<float> a;
+			std::memset(&a, 0, sizeof(a));
+			a.scene = c->blob32.dev; a.prims_off = c->blob32.prims_off; a.mats_off = c->blob32.mats_off; a.gates_off = c->blob32.gates_off;
+			a.scene_bytes = c->blob32.bytes;
+			a.stack_entries = c->tree_depth; fill_camera<float>(c->cam, &a.cam);
+			if (precision == RTHIP_F32) {  // refine the winner in f64; RTHIP_F32_RAW reports the f32 record as it is
+				fill_camera<double>(c->cam, &a.cam64);
+				a.scene64 = c->blob64.dev; a.prims_off64 = c->blob64.prims_off;
+			}
+			a.width = c->cam.width; a.height = c->cam.height; a.seed = seed; a.sample = sample; a.jitter = jitter;
+			a.id = reinterpret_cast<int32_t*>(d); a.t = reinterpret_cast<double*>(d + off_t); a.normal = reinterpret_cast<double*>(d + off_n);
+			a.front = reinterpret_cast<uint8_t*>(d + off_f);
+			e = launch_probe(a, lds, c->stream);
+		}
+		if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+		if (e == hipSuccess) e = hipMemcpy(id, d, n * 4, hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(t, d + off_t, n * 8, hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(normal, d + off_n, n * 24, hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(front_face, d + off_f, n, hipMemcpyDeviceToHost);
+		(void)hipFree(d);
+		HIP_TRY(c, e);
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_render_samples(rthip_ctx* c, const rthip_render_params* p, double* samples) {
-	int32_t rc = validate(c, p);
-	if (rc != RTHIP_OK) return rc;
-	if (!samples) return fail(c, RTHIP_ERR_INVALID, "samples is NULL");
-	if (p->part_count != 1) return fail(c, RTHIP_ERR_INVALID, "the sample probe renders the whole image");
-	HIP_TRY(c, hipSetDevice(c->device));
-	if ((rc = collect_stats(c)) != RTHIP_OK) return rc;
-	size_t n = (size_t)c->cam.width * c->cam.height * 3 * p->spp_count;
-	if (n > (1ull << 31)) return fail(c, RTHIP_ERR_LIMIT, "sample probe is for small images");
-	uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
-	size_t elem = p->precision == RTHIP_F64 ? 8 : 4;
+	if (!c) return RTHIP_ERR_INVALID;
 	char* d_samples = nullptr;
 	unsigned long long* d_scratch = nullptr;
-	HIP_TRY(c, hipMalloc(&d_samples, n * elem));
-	hipError_t e = hipMalloc(&d_scratch, words * 8);
-	if (e != hipSuccess) { (void)hipFree(d_samples); HIP_TRY(c, e); }
-	(void)hipMemsetAsync(d_samples, 0, n * elem, c->stream);
-	(void)hipMemsetAsync(d_scratch, 0, words * 8, c->stream);
-	bool count = env_int("RTHIP_COUNT", 0) != 0;
-	if (p->variant == RTHIP_WAVEFRONT) {
-		if (p->precision == RTHIP_F64) rc = enqueue_wavefront<double>(c, p, d_scratch, reinterpret_cast<double*>(d_samples));
-		else rc = enqueue_wavefront<float>(c, p, d_scratch, reinterpret_cast<float*>(d_samples));
-	} else if (p->precision == RTHIP_F64) rc = enqueue_render<double>(c, p, count, d_scratch, reinterpret_cast<double*>(d_samples));
-	else rc = enqueue_render<float>(c, p, count, d_scratch, reinterpret_cast<float*>(d_samples));
-	if (rc == RTHIP_OK) rc = collect_stats(c);
-	if (rc == RTHIP_OK) {
+	int32_t rc = guarded(c, [&]() -> int32_t {
+		int32_t rc = validate(c, p);
+		if (rc != RTHIP_OK) return rc;
+		if (!samples) return fail(c, RTHIP_ERR_INVALID, "samples is NULL");
+		if (p->part_count != 1) return fail(c, RTHIP_ERR_INVALID, "the sample probe renders the whole image");
+		HIP_TRY(c, hipSetDevice(c->device));
+		if ((rc = collect_stats(c)) != RTHIP_OK) return rc;
+		size_t n = (size_t)c->cam.width * c->cam.height * 3 * p->spp_count;
+		if (n > (1ull << 31)) return fail(c, RTHIP_ERR_LIMIT, "sample probe is for small images");
+		uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
+		size_t elem = p->precision == RTHIP_F64 ? 8 : 4;
+		HIP_TRY(c, hipMalloc(&d_samples, std::max<size_t>(n * elem, 8)));
+		HIP_TRY(c, hipMalloc(&d_scratch, words * 8));
+		HIP_TRY(c, hipMemsetAsync(d_samples, 0, n * elem, c->stream));
+		HIP_TRY(c, hipMemsetAsync(d_scratch, 0, words * 8, c->stream));
+		const bool count = c->tune.count != 0;
+		if (p->variant == RTHIP_WAVEFRONT) {
+			if (p->precision == RTHIP_F64) rc = enqueue_wavefront<double>(c, p, d_scratch, reinterpret_cast<double*>(d_samples));
+			else rc = enqueue_wavefront<float>(c, p, d_scratch, reinterpret_cast<float*>(d_samples));
+		} else if (p->precision == RTHIP_F64) rc = enqueue_render<double>(c, p, count, d_scratch, reinterpret_cast<double*>(d_samples));
+		else rc = enqueue_render<float>(c, p, count, d_scratch, reinterpret_cast<float*>(d_samples));
+		if (rc == RTHIP_OK) rc = collect_stats(c);
+		if (rc != RTHIP_OK) return rc;
 		if (p->precision == RTHIP_F64) {
-			e = hipMemcpy(samples, d_samples, n * 8, hipMemcpyDeviceToHost);
+			HIP_TRY(c, hipMemcpy(samples, d_samples, n * 8, hipMemcpyDeviceToHost));
 		} else {
 			std::vector<float> tmp(n);
-			e = hipMemcpy(tmp.data(), d_samples, n * 4, hipMemcpyDeviceToHost);
+			HIP_TRY(c, hipMemcpy(tmp.data(), d_samples, n * 4, hipMemcpyDeviceToHost));
 			for (size_t i = 0; i < n; i++) samples[i] = (double)tmp[i];
 		}
-		if (e != hipSuccess) rc = fail(c, RTHIP_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
-	}
-	(void)hipFree(d_samples);
-	(void)hipFree(d_scratch);
+		return RTHIP_OK;
+	});
+	// whatever happened above (an exception included), the kernels are done before their buffers go
+	if (d_samples || d_scratch) (void)hipStreamSynchronize(c->stream);
+	if (d_samples) (void)hipFree(d_samples);
+	if (d_scratch) (void)hipFree(d_scratch);
 	return rc;
 }
 
 int32_t rthip_get_stats(rthip_ctx* c, rthip_stats* out) {
 	if (!c || !out) return RTHIP_ERR_INVALID;
-	HIP_TRY(c, hipSetDevice(c->device));
-	int32_t rc = collect_stats(c);
-	if (rc != RTHIP_OK) return rc;
-	*out = c->stats;
-	return RTHIP_OK;
+	return guarded(c, [&]() -> int32_t {
+		HIP_TRY(c, hipSetDevice(c->device));
+		int32_t rc = collect_stats(c);
+		if (rc != RTHIP_OK) return rc;
+		*out = c->stats;
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* ids, int32_t* leaf_sizes, int64_t* n_leaves,
                              int32_t* depth) {
-	if (n < 0 || (n > 0 && !objects)) return fail(nullptr, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
-	if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
-	FlatScene flat;
-	std::string err;
-	if (!build_scene_guarded(objects, n, &flat, &err)) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
-	if (ids) std::copy(flat.leaf_ids.begin(), flat.leaf_ids.end(), ids);
-	if (leaf_sizes) std::copy(flat.leaf_sizes.begin(), flat.leaf_sizes.end(), leaf_sizes);
-	if (n_leaves) *n_leaves = (int64_t)flat.leaf_sizes.size();
-	if (depth) *depth = flat.ref_depth;
-	return RTHIP_OK;
+	return guarded(nullptr, [&]() -> int32_t {
+		if (n < 0 || (n > 0 && !objects)) return fail(nullptr, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
+		if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
+		FlatScene flat;
+		std::string err;
+		if (!build_flat_scene(objects, n, &flat, &err, BuildOptions::from_env())) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+		if (ids) std::copy(flat.leaf_ids.begin(), flat.leaf_ids.end(), ids);
+		if (leaf_sizes) std::copy(flat.leaf_sizes.begin(), flat.leaf_sizes.end(), leaf_sizes);
+		if (n_leaves) *n_leaves = (int64_t)flat.leaf_sizes.size();
+		if (depth) *depth = flat.ref_depth;
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* violations, int32_t* n_nodes, int32_t* depth, uint64_t* checksum) {
-	if (n < 0 || (n > 0 && !objects)) return fail(nullptr, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
-	if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
-	FlatScene flat;
-	std::string err;
-	if (!build_scene_guarded(objects, n, &flat, &err)) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
-	std::string first;
-	const int64_t bad = validate_flat_scene(flat, n, &first);
-	if (violations) *violations = bad;
-	if (n_nodes) *n_nodes = (int32_t)flat.nodes32.size();
-	if (depth) *depth = flat.depth;
-	if (checksum) *checksum = checksum_flat_scene(flat);
-	if (bad) return fail(nullptr, RTHIP_ERR_STATE, first);
-	return RTHIP_OK;
+	return guarded(nullptr, [&]() -> int32_t {
+		if (n < 0 || (n > 0 && !objects)) return fail(nullptr, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
+		if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
+		FlatScene flat;
+		std::string err;
+		if (!build_flat_scene(objects, n, &flat, &err, BuildOptions::from_env())) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+		std::string first;
+		const int64_t bad = validate_flat_scene(flat, n, &first);
+		if (violations) *violations = bad;
+		if (n_nodes) *n_nodes = (int32_t)flat.nodes32.size();
+		if (depth) *depth = flat.depth;
+		if (checksum) *checksum = checksum_flat_scene(flat);
+		if (bad) return fail(nullptr, RTHIP_ERR_STATE, first);
+		return RTHIP_OK;
+	});
+}
+
+int32_t rthip_bvh_gate_count(const rthip_object* objects, int64_t n, int64_t* n_gates, int64_t* n_gated_spheres) {
+	return guarded(nullptr, [&]() -> int32_t {
+		if (n < 0 || (n > 0 && !objects)) return fail(nullptr, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
+		if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
+		FlatScene flat;
+		std::string err;
+		if (!build_flat_scene(objects, n, &flat, &err, BuildOptions::from_env())) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+		int64_t gated = 0;
+		for (const Prim<float>& p : flat.prims32)
+			if (((p.id >> kKindShift) & 1) == RTHIP_SPHERE && prim_gate_count(p) != 0) gated++;
+		if (n_gates) *n_gates = (int64_t)flat.gates32.size();
+		if (n_gated_spheres) *n_gated_spheres = gated;
+		return RTHIP_OK;
+	});
 }
 
 int32_t rthip_scene_generate(const char* name, uint32_t seed, rthip_object* out, int64_t capacity, int64_t* n) {
-	if (!name || !n) return fail(nullptr, RTHIP_ERR_INVALID, "name or n is NULL");
-	std::vector<rthip_object> objs;
-	std::string err;
-	if (!generate_scene(name, seed, &objs, &err)) return fail(nullptr, RTHIP_ERR_INVALID, err);
-	*n = (int64_t)objs.size();
-	if (out && capacity > 0) std::memcpy(out, objs.data(), sizeof(rthip_object) * (size_t)std::min<int64_t>(capacity, *n));
-	return RTHIP_OK;
+	return guarded(nullptr, [&]() -> int32_t {
+		if (!name || !n) return fail(nullptr, RTHIP_ERR_INVALID, "name or n is NULL");
+		std::vector<rthip_object> objs;
+		std::string err;
+		if (!generate_scene(name, seed, &objs, &err)) return fail(nullptr, RTHIP_ERR_INVALID, err);
+		*n = (int64_t)objs.size();
+		if (out && capacity > 0) std::memcpy(out, objs.data(), sizeof(rthip_object) * (size_t)std::min<int64_t>(capacity, *n));
+		return RTHIP_OK;
+	});
 }
 
 void rthip_camera_rotation(double yaw_deg, double pitch_deg, double out[3]) { camera_rotation(yaw_deg, pitch_deg, out); }

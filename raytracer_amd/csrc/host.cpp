@@ -304,13 +304,14 @@ struct Builder {
 	int max_depth = 0;
 	int max_leaf = 4;
 	bool threads_on = true;  // large ranges are built on several threads (same result as on one)
+	bool tie_reverse = false;  // equal sort keys end up in reversed order (the other extreme of what sort_unstable_by may do)
 	int sweep_max = 48;  // exact sweep over sorted centroids up to this many primitives, 32 bins beyond
 	double cost_node = 1.0, cost_prim = 0.4;  // a primitive test against a node visit (two box tests); tuned on MI355X
 
 	struct RefNode { size_t begin, end; int left, right; Box ref; };
 	std::vector<RefNode> ref_nodes;
 	std::vector<int32_t> rank;        // per object id
-	std::vector<uint32_t> gate_word;  // per object id: first gate << 8 | gate count, 0 = none
+	std::vector<uint32_t> gate_first, gate_count;  // per object id: index of its first gate box and how many it has (0 = none)
 
 	// The box the reference caches per object (src/shapes/sphere.rs:19, cube.rs:17): centre
 	// -/+ radius or half extent AS GIVEN, so it is inverted for negative sizes.
@@ -400,7 +401,7 @@ struct Builder {
 		// chasing object records, which is what the build of a million objects spends its time on)
 		sort_keys.resize(len);
 		for (size_t i = 0; i < len; i++) {
-			int32_t id = order[begin + i];
+			int32_t id = order[begin + (tie_reverse ? len - 1 - i : i)];  // a stable sort of the reversed range reverses the ties
 			sort_keys[i] = {ref_min(id, axis) + ref_max(id, axis), id};
 		}
 		auto by_key = [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) { return a.first < b.first; };
@@ -483,7 +484,7 @@ struct Builder {
 					out->gates32.push_back(g32);
 					count++;
 				}
-				if (count) gate_word[(size_t)id] = (first << 8) | count;
+				if (count) { gate_first[(size_t)id] = first; gate_count[(size_t)id] = count; }
 			}
 			*next_rank += k;
 			out->leaf_sizes.push_back(k);
@@ -587,9 +588,9 @@ struct Builder {
 				if (o.kind == RTHIP_SPHERE) {
 					p64.v[3] = o.extent[0];
 					p32.v[3] = (float)o.extent[0];
-					// gate word, carried as a number in the spare slot (exact: < 2^24 in f32 scenes that have gates)
-					p64.v[4] = (double)gate_word[(size_t)id];
-					p32.v[4] = (float)gate_word[(size_t)id];
+					// the sphere's gates, as integers in the two spare slots
+					prim_set_gates(p64, gate_first[(size_t)id], gate_count[(size_t)id]);
+					prim_set_gates(p32, gate_first[(size_t)id], gate_count[(size_t)id]);
 				} else {
 					for (int q = 0; q < 3; q++) {
 						p64.v[3 + q] = o.extent[q];
@@ -754,7 +755,22 @@ struct Builder {
 };
 }  // namespace
 
-bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err) {
+BuildOptions BuildOptions::from_env() {
+	BuildOptions o;
+	if (const char* v = std::getenv("RTHIP_TREE")) o.tree_ref = std::string(v) == "ref";
+	if (const char* v = std::getenv("RTHIP_SAH_LEAF")) o.sah_leaf = std::atoi(v);
+	if (const char* v = std::getenv("RTHIP_SAH_CPRIM")) o.sah_cprim = std::atof(v);
+	if (const char* v = std::getenv("RTHIP_SAH_SWEEP")) o.sah_sweep = std::atoi(v);
+	if (const char* v = std::getenv("RTHIP_BIG_LEAF_MIN")) o.big_leaf_min = std::atoi(v);
+	o.no_big_leaf = std::getenv("RTHIP_NO_BIG_LEAF") != nullptr;
+	o.no_qnodes = std::getenv("RTHIP_NO_QNODES") != nullptr;
+	if (const char* v = std::getenv("RTHIP_BUILD_THREADS")) o.threads = std::atoi(v) != 1;
+	o.timing = std::getenv("RTHIP_BUILD_TIMING") != nullptr;
+	if (const char* v = std::getenv("RTHIP_TIE_REVERSE")) o.tie_reverse = std::atoi(v) != 0;
+	return o;
+}
+
+bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err, const BuildOptions& opt) {
 	*out = FlatScene();
 	if (n <= 0) { *err = "empty scene: BVH::new returns None"; return false; }
 	if (n > kMaxObjects) { *err = "too many objects"; return false; }
@@ -771,7 +787,8 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	b.order.resize((size_t)n);
 	std::iota(b.order.begin(), b.order.end(), 0);
 	b.rank.assign((size_t)n, 0);
-	b.gate_word.assign((size_t)n, 0u);
+	b.gate_first.assign((size_t)n, 0u);
+	b.gate_count.assign((size_t)n, 0u);
 	out->mats64.resize((size_t)n);
 	out->mats32.resize((size_t)n);
 	for (int64_t i = 0; i < n; i++) {
@@ -779,7 +796,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		out->mats64[(size_t)i].param = objs[i].param;
 		out->mats32[(size_t)i].param = (float)objs[i].param;
 	}
-	const bool timing = std::getenv("RTHIP_BUILD_TIMING") != nullptr;
+	const bool timing = opt.timing;
 	auto t_start = std::chrono::steady_clock::now();
 	auto lap = [&](const char* what) {
 		if (!timing) return;
@@ -788,7 +805,8 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		t_start = now;
 	};
 	// 1. the reference's tree: ranks, leaf order, gates
-	if (const char* v = std::getenv("RTHIP_BUILD_THREADS")) b.threads_on = std::atoi(v) != 1;
+	b.threads_on = opt.threads;
+	b.tie_reverse = opt.tie_reverse;
 	int ref_root = b.ref_build(0, (size_t)n);
 	lap("reference tree");
 	{
@@ -796,7 +814,6 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		int32_t next_rank = 0;
 		b.ref_annotate(ref_root, chain, &next_rank);
 	}
-	if (out->gates32.size() >= (1u << 16)) { *err = "too many gated spheres"; return false; }
 	// reference depth in inner-node levels (reported to callers)
 	{
 		std::vector<std::pair<int, int>> todo{{ref_root, 0}};
@@ -811,11 +828,10 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	}
 	lap("ranks, gates, depth");
 	// 2. the device tree
-	const char* mode = std::getenv("RTHIP_TREE");
-	bool use_sah = !(mode && std::string(mode) == "ref");
-	if (const char* v = std::getenv("RTHIP_SAH_LEAF")) b.max_leaf = std::max(1, std::min(7, std::atoi(v)));
-	if (const char* v = std::getenv("RTHIP_SAH_CPRIM")) b.cost_prim = std::atof(v);
-	if (const char* v = std::getenv("RTHIP_SAH_SWEEP")) b.sweep_max = std::atoi(v);
+	bool use_sah = !opt.tree_ref;
+	b.max_leaf = std::max(1, std::min(7, opt.sah_leaf));
+	if (opt.sah_cprim >= 0.0) b.cost_prim = opt.sah_cprim;
+	if (opt.sah_sweep >= 0) b.sweep_max = opt.sah_sweep;
 	bool big_ids_empty = true;
 	int32_t root = 0;
 	Builder::Sub l, r;
@@ -842,14 +858,13 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 			// Small scenes afford the exact sweep everywhere (+3 % on a 500-object scene).  On a million
 			// objects it costs a second of build time and a level of depth (the traversal stack is LDS
 			// that resident waves pay for) without tracing faster.
-			if (m <= 65536 && !std::getenv("RTHIP_SAH_SWEEP")) b.sweep_max = 4096;
+			if (m <= 65536 && opt.sah_sweep < 0) b.sweep_max = 4096;
 			// A few primitives that dwarf the rest (a ground slab, a sun) would stretch the box of every
 			// node above them.  They go into one leaf of their own, the left child of the root, and the
 			// surface-area build runs over the rest (its root is the right child).  Measured: +2.5 % on
 			// the 500-object scenes, +4 % on the million-object one.
 			std::vector<int32_t> big;
-			const char* big_min = std::getenv("RTHIP_BIG_LEAF_MIN");
-			if (m > (size_t)(big_min ? std::atoi(big_min) : 32) && !std::getenv("RTHIP_NO_BIG_LEAF")) {
+			if (m > (size_t)std::max(0, opt.big_leaf_min) && !opt.no_big_leaf) {
 				auto diag = [](const Builder::Item& it) {
 					double dx = it.b.hi[0] - it.b.lo[0], dy = it.b.hi[1] - it.b.lo[1], dz = it.b.hi[2] - it.b.lo[2];
 					return std::sqrt(dx * dx + dy * dy + dz * dz);
@@ -903,7 +918,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		};
 		size_t n_hittable = 0;
 		for (int64_t i = 0; i < n; i++) n_hittable += b.can_be_hit((int32_t)i) ? 1 : 0;
-		if (std::getenv("RTHIP_SAH_CPRIM") || n_hittable * sizeof(Prim<float>) > 64 * 1024) {
+		if (opt.sah_cprim >= 0.0 || n_hittable * sizeof(Prim<float>) > 64 * 1024) {
 			attempt(b.cost_prim);  // as asked, or a scene for global memory: the value tuned there
 		} else {
 			// The finer the tree, the fewer primitive tests per ray (up to a cost of about one
@@ -939,7 +954,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	// 3. large scenes: the quantised copy of the f32 nodes (see QNode).  The grid spans the boxes
 	// of the surface-area tree; the leaf of oversized primitives stays outside it (node 0, which
 	// holds that leaf and the tree's root, is then not part of the quantised traversal).
-	if (use_sah && out->nodes32.size() > 2048 && !std::getenv("RTHIP_NO_QNODES")) {
+	if (use_sah && out->nodes32.size() > 2048 && !opt.no_qnodes) {
 		const Node<float>& n0 = out->nodes32[0];
 		const bool has_big = !big_ids_empty;
 		// planes of child c of an f32 node (stored as centre and half extent) on axis k; an empty box has lo > hi

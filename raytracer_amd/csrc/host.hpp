@@ -44,8 +44,25 @@ struct FlatScene {
 	std::vector<int32_t> leaf_ids;    // reference tree: object ids, leaves left to right, reference order inside a leaf
 	std::vector<int32_t> leaf_sizes;
 };
+// Knobs of the host build.  A context reads them from the RTHIP_* environment ONCE, when it is
+// created (rthip_set_option changes them afterwards); the host-only entry points, which have no
+// context, read the environment per call.
+struct BuildOptions {
+	bool tree_ref = false;     // RTHIP_TREE=ref: the device tree keeps the reference's shape (default: surface-area build)
+	int sah_leaf = 4;          // RTHIP_SAH_LEAF: largest leaf of the surface-area build, 1..7
+	double sah_cprim = -1.0;   // RTHIP_SAH_CPRIM: cost of a primitive test against a node visit; < 0 = chosen per scene
+	int sah_sweep = -1;        // RTHIP_SAH_SWEEP: exact sweep up to this many primitives per range; < 0 = chosen per scene
+	int big_leaf_min = 32;     // RTHIP_BIG_LEAF_MIN: scenes larger than this may get the leaf of oversized primitives
+	bool no_big_leaf = false;  // RTHIP_NO_BIG_LEAF
+	bool no_qnodes = false;    // RTHIP_NO_QNODES
+	bool threads = true;       // RTHIP_BUILD_THREADS=1 switches the threaded build off
+	bool timing = false;       // RTHIP_BUILD_TIMING: lap times on stderr
+	bool tie_reverse = false;  // RTHIP_TIE_REVERSE: objects with equal sort keys in BVH::new end up in reversed instead of
+	                           // kept order (sort_unstable_by, src/bvh.rs:49, leaves their order open)
+	static BuildOptions from_env();
+};
 // Returns false (with a message) for an empty scene or non-finite input.
-bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err);
+bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err, const BuildOptions& opt);
 // Checks the invariant every culling decision rests on: each f32 child box (centre and half
 // extent), and each quantised one, contains the f32 bounds of every primitive below it; every
 // primitive that can be hit is in exactly one leaf; the tree is no deeper than reported.

@@ -89,6 +89,12 @@ struct ProbeArgs {
 	double* t;
 	double* normal;
 	uint8_t* front;
+	// f32 probe only: the f64 camera and the f64 primitive records (same indices as the f32 ones).
+	// With scene64 set, the primitive the f32 traversal found is intersected once more in f64 from
+	// the f64 camera ray, and t, normal and front face are reported from that.
+	CameraT<double> cam64;
+	const char* scene64;
+	uint32_t prims_off64;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -106,6 +112,7 @@ template <> struct Fp<float> {
 	static __device__ __forceinline__ float fabs(float a) { return __builtin_fabsf(a); }
 	static __device__ __forceinline__ float copysign(float a, float b) { return __builtin_copysignf(a, b); }
 	static __device__ __forceinline__ float inf() { return __builtin_inff(); }
+	static __device__ __forceinline__ float max_finite() { return 3.402823466e+38f; }
 };
 template <> struct Fp<double> {
 	static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
@@ -116,6 +123,7 @@ template <> struct Fp<double> {
 	static __device__ __forceinline__ double fabs(double a) { return __builtin_fabs(a); }
 	static __device__ __forceinline__ double copysign(double a, double b) { return __builtin_copysign(a, b); }
 	static __device__ __forceinline__ double inf() { return __builtin_inf(); }
+	static __device__ __forceinline__ double max_finite() { return 1.7976931348623157e+308; }
 };
 
 // src/math.rs:18-318
@@ -450,7 +458,7 @@ template <typename Real> struct Trav {
 	int32_t best_prim;  // index into prims, -1 = none
 };
 RT_FN void trav_begin(Trav<Real>& tv) {
-	tv.cur = 0; tv.sp = 0; tv.best_t = Fp<Real>::inf(); tv.best_prim = -1;
+	tv.cur = 0; tv.sp = 0; tv.best_t = Fp<Real>::max_finite(); tv.best_prim = -1;
 }
 struct Tally { uint32_t box, sphere, cube; };
 // Instrumented builds only: per code region, the lane-iterations executed (sum over active
@@ -549,8 +557,11 @@ __device__ __forceinline__ void leaf_tests(Trav<Real>& tv, const TravRay<Real>& 
 	region_tick<kCount>(rg, kRegLeaf);
 	const uint32_t code = ~(uint32_t)leaf;
 	const int32_t first = (int32_t)(code >> 6), ns = (int32_t)((code >> 3) & 7u), nc = (int32_t)(code & 7u);
+	// Scene::hit accepts t > 0.001 && t < closest with closest starting at Scalar::MAX (src/scene.rs:102-105):
+	// best_t starts at the largest finite value, so an infinite t never counts; among equal t the
+	// larger rank wins, and there is nothing to tie with while no primitive has been accepted.
 	auto better = [&](Real t, int32_t i) {
-		return t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && prims[i].rank > prims[tv.best_prim].rank));
+		return t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && tv.best_prim >= 0 && prims[i].rank > prims[tv.best_prim].rank));
 	};
 	for (int32_t k = 0; k < ns; k++) {
 		int32_t i = first + k;
@@ -612,7 +623,10 @@ RT_FN Hit<Real> make_hit(const Prim<Real>& pr, bool is_sphere, const TravRay<Rea
 	return h;
 }
 
-// Material::reflectance, src/materials.rs:80-85 (Schlick); (1-cos)^5 as a multiply chain.
+// Material::reflectance, src/materials.rs:80-85 (Schlick).  One departure from the reference in BOTH
+// precisions: (1 - cos)^5 is a multiply chain here where the reference calls powf(5.); the two agree
+// to a few ulps, not bit for bit, which is why per-sample radiance is compared bit-exactly only with
+// a CPU run that uses the same chain, and to 1e-12 relative with one that calls pow().
 RT_FN Real reflectance(Real cosine, Real ref_idx) {
 	Real r0;
 	if constexpr (std::is_same<Real, float>::value) r0 = (1.0f - ref_idx) * Fp<float>::rcp(1.0f + ref_idx);
@@ -960,6 +974,27 @@ __global__ __launch_bounds__(kProbeBlock) void probe_kernel(ProbeArgs<Real> A) {
 		return;
 	}
 	const Prim<Real>& pr = prims[tv.best_prim];
+	if constexpr (std::is_same<Real, float>::value) {
+		// BVH::trace (src/bvh.rs:133-139) for the winning primitive in the reference's own arithmetic:
+		// which primitive is closest is decided in f32, how far it is and which way its surface faces
+		// is then one f64 sphere or cube test (vector f64 runs at half the f32 rate: one test per
+		// ray is nothing).  If the f64 ray misses that primitive (a silhouette pixel), the f32 record stands.
+		if (A.scene64) {
+			Rng rng64;
+			rng64.init(A.seed, i, A.sample);
+			const TravRay<double> ray64 = prepare<double>(camera_ray<double>(A.cam64, (double)px, (double)py, rng64, A.jitter != 0));
+			const Prim<double>& p64 = reinterpret_cast<const Prim<double>*>(A.scene64 + A.prims_off64)[tv.best_prim];
+			const bool sphere = ((p64.id >> kKindShift) & 1) == RTHIP_SPHERE;
+			double t64 = 0.0;
+			const bool ok = sphere ? hit_sphere<double>(p64, ray64, &t64) : hit_cube<double>(p64, ray64, &t64);
+			if (ok && t64 > 0.001 && t64 < Fp<double>::max_finite()) {
+				const Hit<double> h64 = make_hit<double>(p64, sphere, ray64, t64);
+				A.id[i] = h64.id; A.t[i] = t64; A.front[i] = h64.front ? 1 : 0;
+				A.normal[3 * (size_t)i] = h64.n.x; A.normal[3 * (size_t)i + 1] = h64.n.y; A.normal[3 * (size_t)i + 2] = h64.n.z;
+				return;
+			}
+		}
+	}
 	Hit<Real> h = make_hit<Real>(pr, ((pr.id >> kKindShift) & 1) == RTHIP_SPHERE, ray, tv.best_t);
 	A.id[i] = h.id; A.t[i] = (double)tv.best_t; A.front[i] = h.front ? 1 : 0;
 	A.normal[3 * (size_t)i] = (double)h.n.x; A.normal[3 * (size_t)i + 1] = (double)h.n.y; A.normal[3 * (size_t)i + 2] = (double)h.n.z;

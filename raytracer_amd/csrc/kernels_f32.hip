@@ -1,4 +1,6 @@
 // kernels_f32.hip — production instantiation: f32 VALU arithmetic, fp contraction allowed.
+#include <mutex>
+
 #include "launch.hpp"
 #define RT_REAL float
 #include "kernels_impl.inc"
@@ -42,6 +44,29 @@ hipError_t launch_finalize(const unsigned long long* accum, void* out, int width
 
 hipError_t wf_extend_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks) { return wf_extend_blocks_per_cu_impl(threads, scene_in_lds, dyn_lds, blocks); }
 hipError_t render_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks, bool quantised) { return blocks_per_cu_impl(threads, scene_in_lds, dyn_lds, blocks, quantised); }
+
+// Static scratch (see launch.hpp).  In host code the array's name is only a handle for
+// hipGetSymbolAddress; kernels and memsets get the per-device address looked up here.
+static __device__ __attribute__((used)) __align__(256) unsigned char scratch[kStaticScratchBytes];
+hipError_t static_scratch_for_device(int device, void** ptr) {
+	constexpr int kMaxDevices = 64;
+	static std::mutex mu;
+	static void* table[kMaxDevices] = {};
+	if (!ptr || device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+	std::lock_guard<std::mutex> lock(mu);
+	if (!table[device]) {
+		int current = -1;
+		hipError_t e = hipGetDevice(&current);
+		if (e != hipSuccess) return e;
+		if (current != device) return hipErrorInvalidDevice;  // the lookup answers for the current device
+		void* p = nullptr;
+		e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+		if (e != hipSuccess) return e;
+		table[device] = p;
+	}
+	*ptr = table[device];
+	return hipSuccess;
+}
 
 hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x, hipStream_t s) {
 	unsigned n = (unsigned)width * (unsigned)height;

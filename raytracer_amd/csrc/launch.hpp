@@ -31,6 +31,14 @@ hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width
 hipError_t launch_finalize(const unsigned long long* accum, void* out, int width, int height, int tiles_x, unsigned spp, int xrgb, hipStream_t s);
 
 
+// A small array in static device memory (file scope of kernels_f32.hip), for the entry point that
+// must not allocate: it holds the control block of a launch (statistics and work-queue
+// counters), which every other entry point keeps in memory allocated at rthip_create.  Each GPU
+// has its own copy at its own address: `device` must be the current device; the address is
+// looked up once per device and kept.
+constexpr size_t kStaticScratchBytes = 4096;
+hipError_t static_scratch_for_device(int device, void** ptr);
+
 // Wavefront variant: one launcher per stage.  `grid` = workgroups of kWfStreamThreads for the
 // streaming stages; extend is configured like the megakernel (threads, dynamic LDS, scene in LDS).
 hipError_t launch_wf_generate(const WfArgs<float>& a, int grid, hipStream_t s);

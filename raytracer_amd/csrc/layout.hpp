@@ -57,7 +57,9 @@ struct QFrame {
 constexpr int kQMax = 32767;
 static_assert(sizeof(Node<double>) == 128, "f64 node is 128 bytes");
 
-// Sphere: v = centre.xyz, radius, gate word (see Gate), 0.
+// Sphere: v = centre.xyz, radius; the slots v[4] and v[5] carry two INTEGERS in their low 32 bits
+//         (not numbers: read them with prim_gate_first / prim_gate_count): the index of the
+//         sphere's first gate box and the number of its gate boxes (see Gate), 0 and 0 for none.
 // Cube, f64: v = centre.xyz, half_extent.xyz (the reference's own representation).
 // Cube, f32: v = the six face planes lo.xyz, hi.xyz (the order of kBox*), computed
 //            in f64 as centre -/+ half_extent and rounded once, so that huge cubes (ground slabs
@@ -69,6 +71,19 @@ struct alignas(sizeof(Real) * 8) Prim {
 	int32_t rank;  // tie rank: among equal t the larger rank wins
 };
 static_assert(sizeof(Prim<float>) == 32, "f32 primitive is 32 bytes");
+// The integer slots of a sphere (little endian: the low word of the slot in either precision).
+#if defined(__HIPCC__) || defined(__HIP__)
+#define RT_LAYOUT_FN __host__ __device__ inline
+#else
+#define RT_LAYOUT_FN inline
+#endif
+template <typename Real> RT_LAYOUT_FN uint32_t prim_gate_first(const Prim<Real>& p) { uint32_t w; __builtin_memcpy(&w, &p.v[4], 4); return w; }
+template <typename Real> RT_LAYOUT_FN uint32_t prim_gate_count(const Prim<Real>& p) { uint32_t w; __builtin_memcpy(&w, &p.v[5], 4); return w; }
+template <typename Real> RT_LAYOUT_FN void prim_set_gates(Prim<Real>& p, uint32_t first, uint32_t count) {
+	p.v[4] = Real(0); p.v[5] = Real(0);
+	__builtin_memcpy(&p.v[4], &first, 4);
+	__builtin_memcpy(&p.v[5], &count, 4);
+}
 static_assert(sizeof(Prim<double>) == 64, "f64 primitive is 64 bytes");
 
 // Gate box.  BVH::new (src/bvh.rs:53-56,68) unions the boxes objects cache, and a sphere of
@@ -77,9 +92,9 @@ static_assert(sizeof(Prim<double>) == 64, "f64 primitive is 64 bytes");
 // shell that would have covered it, the reference's boxes above it are smaller than its true
 // bounds, and the reference reaches it only for rays that pass its per-axis test
 // (src/math.rs:356-371) on those boxes.  Such a sphere carries those boxes as gates and counts
-// as hit only if the ray passes the reference's test on each of them (Prim::v[4] of a sphere
-// holds first_gate << 8 | n_gates as a number).  For every other object that test is implied
-// by hitting the object, and nothing is stored.
+// as hit only if the ray passes the reference's test on each of them (the integer slots of a
+// sphere's Prim say which).  For every other object that test is implied by hitting the
+// object, and nothing is stored.
 template <typename Real>
 struct Gate {
 	Real box[6];  // lo.xyz hi.xyz as the reference computes them

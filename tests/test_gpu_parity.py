@@ -12,14 +12,19 @@ from util import SCENES, camera_args
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# f32 (production) tolerances, stated here.  The f64 path meets "t and normal within 1e-5" literally
-# (it is bit-exact).  In f32 the primary ray itself is rounded (direction to ~1e-7), and the
-# distance to a surface seen at grazing incidence amplifies that by 1 / |cos(incidence)| (a ray
-# skimming the ground slab toward the horizon has |cos| ~ 1e-4), which no f32 formulation can
-# avoid.  So t is held to 1e-5 relative scaled by that conditioning factor, and the median and
-# the 99th percentile are bounded outright.  Normals (sphere: position error / radius) likewise:
-# 5e-5 absolute per component scaled by the same factor, 2e-5 at the 99th percentile.
+# f32 (production) tolerances, stated here.
+# Hit ids: the bar is "bit-exact"; on the six reference scenes the f32 traversal finds the oracle's
+# object on every pixel (0 mismatches asserted); random adversarial scenes keep a silhouette bound.
+# t and normal: the bar is 1e-5 relative.  The probe decides WHICH primitive is closest in f32 and
+# then intersects that one primitive again in f64 from the f64 camera ray (rthip.h, RTHIP_F32), so
+# its record meets the bar literally.  The raw f32 record (RTHIP_F32_RAW: what the render kernel
+# works with) cannot: the primary ray itself is rounded (direction to ~1e-7), and the distance
+# to a surface seen at grazing incidence amplifies that by 1 / |cos(incidence)| (a ray skimming
+# the ground slab toward the horizon has |cos| ~ 1e-4).  The raw record is held to 1e-5 scaled by
+# that conditioning factor, its median and 99th percentile are bounded outright, and the number of
+# pixels over the literal bar is printed per scene.
 F32_T_RTOL, F32_T_P50, F32_T_P99, F32_N_ATOL, F32_N_P99 = 1e-5, 2e-7, 5e-6, 5e-5, 2e-5
+LITERAL_BAR = 1e-5
 
 
 @pytest.fixture(scope="module")
@@ -59,17 +64,37 @@ def test_f64_probe_bit_exact_vs_golden_and_oracle(rt, oracle, renderers, scene):
 
 
 @pytest.mark.parametrize("scene", SCENES)
-def test_f32_probe_within_tolerance(rt, oracle, renderers, scene):
+def test_f32_probe_meets_the_literal_bar(rt, oracle, renderers, scene):
+    """Primary-hit ids equal on every pixel; t and normal within 1e-5 relative, no conditioning
+    factor (the f32 probe re-intersects the winning primitive in f64)."""
     r, sc = renderers(scene, 320, 180, seed=5)
     osc = oracle.OracleScene(sc.objects)
     cam = oracle.camera_desc(*camera_args(scene, 320, 180, rt))
     for jit in (False, True):
         rid, rtt, rn, rf = osc.trace_primary(cam, oracle.TIGHT, jitter=jit, seed=5, sample=9)
         gid, gt, gn, gf = r.trace_primary(rt.F32, jitter=jit, sample=9)
+        assert int((rid != gid).sum()) == 0, f"{(rid != gid).sum()} primary-hit ids differ"
+        hit = rid >= 0
+        rel = np.abs(gt - rtt)[hit] / rtt[hit]
+        assert rel.max() <= LITERAL_BAR, float(rel.max())
+        assert np.abs(gn - rn)[hit].max() <= LITERAL_BAR
+        assert np.array_equal(gf, rf)
+        assert not gt[~hit].any() and not gn[~hit].any()
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_f32_raw_probe_within_conditioned_tolerance(rt, oracle, renderers, scene):
+    """The f32 record as the render kernel sees it: ids equal everywhere, t and normal within
+    1e-5 x 1 / |cos(incidence)|; how many pixels exceed the literal 1e-5 is printed."""
+    r, sc = renderers(scene, 320, 180, seed=5)
+    osc = oracle.OracleScene(sc.objects)
+    cam = oracle.camera_desc(*camera_args(scene, 320, 180, rt))
+    for jit in (False, True):
+        rid, rtt, rn, rf = osc.trace_primary(cam, oracle.TIGHT, jitter=jit, seed=5, sample=9)
+        gid, gt, gn, gf = r.trace_primary(rt.F32_RAW, jitter=jit, sample=9)
         _, dirs = oracle.camera_rays(cam, 5, 9, jit)
-        mismatch = rid != gid
-        assert mismatch.mean() <= 2e-4, f"{mismatch.sum()} primary-hit ids differ"   # silhouette pixels only
-        same = (~mismatch) & (rid >= 0)
+        assert int((rid != gid).sum()) == 0, f"{(rid != gid).sum()} primary-hit ids differ"
+        same = rid >= 0
         rel = np.abs(gt - rtt)[same] / rtt[same]
         cos = np.abs((dirs * rn).sum(axis=-1))[same]          # primary directions are unit length
         assert (rel <= F32_T_RTOL / np.maximum(cos, 1e-6)).all(), float((rel * cos).max())
@@ -78,6 +103,8 @@ def test_f32_probe_within_tolerance(rt, oracle, renderers, scene):
         assert (dn <= F32_N_ATOL / np.maximum(cos, 1e-6)).all(), float((dn * cos).max())
         assert np.percentile(dn, 99) <= F32_N_P99
         assert np.array_equal(gf[same], rf[same])
+        print(f"[f32 raw] {scene} jitter={int(jit)}: {int((rel > LITERAL_BAR).sum())} of {int(same.sum())} hit pixels over 1e-5 in t "
+              f"(max {rel.max():.2e}), {int((dn > LITERAL_BAR).sum())} in a normal component (max {dn.max():.2e})")
 
 
 @pytest.mark.parametrize("scene", SCENES)
@@ -222,6 +249,7 @@ def test_caller_owned_accumulation_buffer(rt, renderers):
     r.reset_accumulation(); r.accumulate(2)
     own = r.read_accum()
     buf = D.new_accum_tensor(w, h, "cuda:0")
+    torch.cuda.synchronize()     # the zero-fill ran on torch's stream, the render runs on the context's own
     r.set_accum_buffer(buf.data_ptr(), buf.numel())
     r.accumulate(2, spp_begin=0)
     torch.cuda.synchronize()
@@ -399,18 +427,14 @@ def test_quantised_nodes_change_no_path(rt):
     """Large f32 scenes are traversed over 32-byte quantised nodes whose boxes contain the full
     boxes, with the oversized primitives in a leaf of their own: the primitive tests, and so
     every path, must come out bit for bit as over the full nodes."""
-    import os
     sc = rt.create_synthetic_scene(60_000, seed=5)
     cam = rt.Camera((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0, 160, 90)
     r = rt.Renderer(sc, cam, max_depth=12, seed=3)
-    try:
-        os.environ["RTHIP_COUNT"] = "1"
-        os.environ["RTHIP_QNODES"] = "0"
-        full = r.render_samples(3, precision=rt.F32); c_full = r.stats()
-        os.environ["RTHIP_QNODES"] = "1"
-        quant = r.render_samples(3, precision=rt.F32); c_q = r.stats()
-    finally:
-        os.environ.pop("RTHIP_QNODES", None); os.environ.pop("RTHIP_COUNT", None)
+    r.set_option("count", 1)
+    r.set_option("qnodes", 0)
+    full = r.render_samples(3, precision=rt.F32); c_full = r.stats()
+    r.set_option("qnodes", 1)
+    quant = r.render_samples(3, precision=rt.F32); c_q = r.stats()
     assert c_q["scene_in_lds"] == 0 and c_q["rays"] == c_full["rays"]
     assert np.array_equal(full, quant)
     # the coarser boxes cost a few extra tests, skipping the root's node saves two per ray
@@ -478,14 +502,14 @@ def test_tree_fineness_follows_the_lds_budget(rt):
 
 
 @pytest.mark.gpu
-def test_tile_block_order_changes_no_image(rt, monkeypatch):
+def test_tile_block_order_changes_no_image(rt):
     """Scenes in global memory run their work items through the image in blocks of tiles; the
     order (any block size, ragged image edges included) changes no accumulated word."""
     cam = rt.Camera((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0, 701, 333)
     r = rt.Renderer(rt.create_synthetic_scene(5000, seed=3), cam, max_depth=8, seed=9)
     images = []
-    for block in ("0", "32", "5", "1", "1000"):
-        monkeypatch.setenv("RTHIP_BLOCK_ORDER", block)
+    for block in (0, 32, 5, 1, 1000):
+        r.set_option("block_order", block)
         r.reset_accumulation(); r.accumulate(3)
         assert r.stats()["scene_in_lds"] == 0
         images.append(r.read_accum())

@@ -1,0 +1,61 @@
+"""rthip_render_accumulate_noalloc: the render call that allocates nothing (its control block lives
+in a static device array instead of memory from hipMalloc) against rthip_render_accumulate, bit for
+bit, on two calls in a row, the second on a smaller input."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import camera_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _words(r):
+    _, n = r.accum_buffer()
+    w = np.zeros(n, dtype=np.uint64)
+    r._check(r._lib.rthip_accum_download(r._ctx, w.ctypes.data, n))
+    return w
+
+
+def test_noalloc_entry_point_matches_the_allocating_one(rt):
+    from raytracer_amd import _native as N
+    sc = rt.Scene.generate("default")
+    r = rt.Renderer(sc, rt.Camera(*camera_args("default", 640, 360, rt)), seed=41)
+    # two calls in a row through the static scratch; the second on a smaller frame with fewer samples
+    for (w, h, spp, prec) in ((640, 360, 6, rt.F32), (200, 120, 3, rt.F32), (96, 54, 2, rt.F64)):
+        r.update_camera(rt.Camera(*camera_args("default", w, h, rt)))
+        r.precision = prec
+        r.accumulate(spp, spp_begin=0)
+        want, want_stats = _words(r), r.stats()
+        r.reset_accumulation()
+        r.accumulate(spp, spp_begin=0, noalloc=True)
+        got, got_stats = _words(r), r.stats()
+        assert np.array_equal(got, want), (w, h, spp)
+        assert got_stats["paths"] == want_stats["paths"] == w * h * spp and got_stats["rays"] == want_stats["rays"]
+    # back to back without a host wait in between, then the allocating call again: the blocks do not mix
+    r.precision = rt.F32
+    r.reset_accumulation()
+    r.accumulate(2, spp_begin=0, noalloc=True, sync=False)
+    r.accumulate(1, spp_begin=2, noalloc=True, sync=False)
+    r.synchronize()
+    assert r.stats()["paths"] == 96 * 54
+    three = _words(r)
+    r.reset_accumulation(); r.accumulate(3, spp_begin=0)
+    assert np.array_equal(_words(r), three)
+    # what it cannot do without allocating is refused with a message, not done by allocating
+    p = r._params(0, 1)
+    p.variant = rt.WAVEFRONT
+    assert r._lib.rthip_render_accumulate_noalloc(r._ctx, C.byref(p)) == N.ERR_LIMIT
+    assert b"wavefront" in r._lib.rthip_last_error(r._ctx)
+    r.close()
+    # a caller-owned accumulation buffer, a second context on the same device: same scratch, same result
+    import torch
+    from raytracer_amd import distributed as D
+    r2 = rt.Renderer(sc, rt.Camera(*camera_args("default", 96, 54, rt)), seed=41)
+    buf = D.new_accum_tensor(96, 54, "cuda:0")
+    torch.cuda.synchronize()
+    r2.set_accum_buffer(buf.data_ptr(), buf.numel())
+    r2.accumulate(3, spp_begin=0, noalloc=True)
+    assert np.array_equal(buf.cpu().numpy().view(np.uint64), three)
+    r2.close()
