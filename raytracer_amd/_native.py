@@ -78,6 +78,26 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own HIP and HSA runtimes (torch/lib), with the same sonames as
+    the system's.  A process must run ONE of them: if librthip.so pulled in the system runtime
+    first, a later `import torch` finds no GPU.  So when PyTorch is installed, its runtime is
+    loaded before librthip.so, whose dependency then resolves to it by soname.  (Nothing of
+    PyTorch itself is imported.)"""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded library; raises if it has not been built."""
     global _lib
@@ -86,6 +106,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         handle = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SYMBOLS.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported

@@ -570,9 +570,9 @@ __device__ __forceinline__ void leaf_tests(Trav<Real>& tv, const TravRay<Real>& 
 		if (kCount) tally.sphere++;
 		if (hit_sphere<Real>(prims[i], r, &t) && better(t, i)) {
 			// a gated (inverted) sphere counts only if the reference would have reached it
-			uint32_t gw = (uint32_t)prims[i].v[4];
+			const uint32_t n_gates = prim_gate_count(prims[i]), first_gate = prim_gate_first(prims[i]);
 			bool reachable = true;
-			for (uint32_t g = 0; g < (gw & 255u); g++) reachable = reachable && hit_box_reference<Real>(gates[(gw >> 8) + g].box, r);
+			for (uint32_t g = 0; g < n_gates; g++) reachable = reachable && hit_box_reference<Real>(gates[first_gate + g].box, r);
 			if (reachable) { tv.best_t = t; tv.best_prim = i; }
 		}
 	}
