@@ -166,6 +166,26 @@ int32_t rthip_set_accum_buffer(rthip_ctx* ctx, void* device_ptr, uint64_t n_word
 int32_t rthip_accum_download(rthip_ctx* ctx, uint64_t* words, uint64_t n_words);
 int32_t rthip_accum_upload(rthip_ctx* ctx, const uint64_t* words, uint64_t n_words);
 
+/* Multi-GPU merge (no counterpart in the reference, a single-process renderer).  Every GPU
+ * renders its share (a tile part or a sample range, see rthip_render_params) into its own
+ * full-frame accumulation buffer; the image is the element-wise sum of those buffers.
+ *
+ * Over RCCL/xGMI, one context per GPU, in one process (one thread per context) or in several:
+ * rank 0 makes an id with rthip_comm_unique_id and hands the 128 bytes to the others by any
+ * means; every rank calls rthip_comm_init(ctx, id, rank, world) (collective: all ranks must be
+ * in the call at once); rthip_merge_reduce then enqueues ONE ncclReduce(sum, uint64) of the
+ * accumulation buffer, in place, on the context's stream, behind the renders already queued;
+ * root = the rank that ends with the image, or -1 for all of them (all-reduce).  Integer sums:
+ * the merged words equal a single GPU's, bit for bit.  librccl is looked up at the first call
+ * (RTHIP_ERR_STATE when the host has none). */
+int32_t rthip_comm_unique_id(uint8_t id[128]);
+int32_t rthip_comm_init(rthip_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t world);
+int32_t rthip_merge_reduce(rthip_ctx* ctx, int32_t root);
+/* The same sum without RCCL, for contexts of ONE process called from one thread (several GPUs,
+ * or several contexts on one GPU): adds the accumulation buffers of ctxs[0..n) into
+ * ctxs[root]'s (peer copies over xGMI where the GPUs differ) and waits for the result. */
+int32_t rthip_merge_local(rthip_ctx* const* ctxs, int32_t n, int32_t root);
+
 /* Read back sum_s sqrt(sample) per channel, row-major [height][width][3] (the Vec<Vec3>
  * `output` of raytracer_headless/src/main.rs:34 before the division of :55). */
 int32_t rthip_read_accum(rthip_ctx* ctx, double* rgb);

@@ -135,6 +135,15 @@ class Camera:
         return d
 
 
+def merge_local(renderers, root=0):
+    """Sums the accumulation buffers of several Renderers of ONE process into renderers[root]'s
+    (rthip_merge_local: peer copies and an add kernel, no RCCL)."""
+    arr = (C.c_void_p * len(renderers))(*[r._ctx for r in renderers])
+    code = N.lib().rthip_merge_local(arr, len(renderers), int(root))
+    if code != N.OK:
+        renderers[root]._raise(code)
+
+
 def bvh_gate_count(scene):
     """(gate boxes, gated spheres) of the scene's build (rthip_bvh_gate_count; host only)."""
     g, s = C.c_int64(0), C.c_int64(0)
@@ -255,6 +264,24 @@ class Renderer:
 
     def set_accum_buffer(self, device_ptr, n_words):
         self._check(self._lib.rthip_set_accum_buffer(self._ctx, C.c_void_p(device_ptr), n_words))
+
+    # ---- multi-GPU merge behind the C ABI (rthip_comm_* / rthip_merge_* in include/rthip.h) ----
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes that rank 0 makes and hands to every other rank."""
+        buf = (C.c_uint8 * 128)()
+        N.check(N.lib().rthip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        """Collective over all ranks: this context becomes rank `rank` of `world` GPUs (RCCL)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.rthip_comm_init(self._ctx, buf, int(rank), int(world)))
+
+    def merge_reduce(self, root=0):
+        """One ncclReduce (root >= 0) or ncclAllReduce (root = -1) of the accumulation buffer, in
+        place, enqueued behind the renders on this context's stream."""
+        self._check(self._lib.rthip_merge_reduce(self._ctx, int(root)))
 
     def save_checkpoint(self, path):
         """Writes the accumulation words and the sample count to an .npz file; load_checkpoint on a

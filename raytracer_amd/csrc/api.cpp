@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/rthip.h"
+#include "comm.hpp"
 #include "host.hpp"
 #include "launch.hpp"
 
@@ -107,6 +108,8 @@ struct rthip_ctx {
 	rthip_stats stats{};
 	bool launch_pending = false;
 	bool last_in_lds = false;
+	ncclComm_t comm = nullptr;  // this context's rank in a communicator of GPUs (rthip_comm_init)
+	int comm_rank = -1, comm_world = 0;
 };
 
 namespace {
@@ -474,6 +477,9 @@ void rthip_destroy(rthip_ctx* c) {
 		(void)hipSetDevice(c->device);
 		if (c->stream) (void)hipStreamSynchronize(c->stream);
 		if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
+		if (c->comm) {
+			if (const RcclApi* rccl = RcclApi::get(nullptr)) (void)rccl->CommDestroy(c->comm);
+		}
 		if (c->blob32.dev) (void)hipFree(c->blob32.dev);
 		if (c->blob64.dev) (void)hipFree(c->blob64.dev);
 		if (c->own_accum) (void)hipFree(c->own_accum);
@@ -666,6 +672,92 @@ int32_t rthip_reset_accumulation(rthip_ctx* c) {
 		HIP_TRY(c, hipMemsetAsync(c->accum, 0, c->accum_words * 8, c->stream));
 		return RTHIP_OK;
 	});
+}
+
+int32_t rthip_comm_unique_id(uint8_t id[128]) {
+	return guarded(nullptr, [&]() -> int32_t {
+		if (!id) return fail(nullptr, RTHIP_ERR_INVALID, "id is NULL");
+		std::string why;
+		const RcclApi* rccl = RcclApi::get(&why);
+		if (!rccl) return fail(nullptr, RTHIP_ERR_STATE, why);
+		static_assert(sizeof(ncclUniqueId) == 128, "RCCL's unique id is 128 bytes");
+		ncclUniqueId u;
+		ncclResult_t r = rccl->GetUniqueId(&u);
+		if (r != ncclSuccess) return fail(nullptr, RTHIP_ERR_HIP, std::string("ncclGetUniqueId: ") + rccl->GetErrorString(r));
+		std::memcpy(id, &u, 128);
+		return RTHIP_OK;
+	});
+}
+
+int32_t rthip_comm_init(rthip_ctx* c, const uint8_t id[128], int32_t rank, int32_t world) {
+	if (!c) return RTHIP_ERR_INVALID;
+	return guarded(c, [&]() -> int32_t {
+		if (!id || world < 1 || rank < 0 || rank >= world) return fail(c, RTHIP_ERR_INVALID, "bad communicator id, rank or size");
+		std::string why;
+		const RcclApi* rccl = RcclApi::get(&why);
+		if (!rccl) return fail(c, RTHIP_ERR_STATE, why);
+		HIP_TRY(c, hipSetDevice(c->device));
+		if (c->comm) { (void)rccl->CommDestroy(c->comm); c->comm = nullptr; }
+		ncclUniqueId u;
+		std::memcpy(&u, id, 128);
+		ncclResult_t r = rccl->CommInitRank(&c->comm, world, u, rank);
+		if (r != ncclSuccess) { c->comm = nullptr; return fail(c, RTHIP_ERR_HIP, std::string("ncclCommInitRank: ") + rccl->GetErrorString(r)); }
+		c->comm_rank = rank; c->comm_world = world;
+		return RTHIP_OK;
+	});
+}
+
+int32_t rthip_merge_reduce(rthip_ctx* c, int32_t root) {
+	if (!c) return RTHIP_ERR_INVALID;
+	return guarded(c, [&]() -> int32_t {
+		if (!c->comm) return fail(c, RTHIP_ERR_STATE, "no communicator: call rthip_comm_init first");
+		if (root < -1 || root >= c->comm_world) return fail(c, RTHIP_ERR_INVALID, "root is not a rank of the communicator");
+		if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
+		const RcclApi* rccl = RcclApi::get(nullptr);
+		HIP_TRY(c, hipSetDevice(c->device));
+		int32_t rc = ensure_accum(c);
+		if (rc != RTHIP_OK) return rc;
+		// In place, in stream order behind the renders that filled the buffer: sums of 64-bit integers
+		// are exact and independent of the order RCCL adds them in.
+		ncclResult_t r = root < 0 ? rccl->AllReduce(c->accum, c->accum, (size_t)c->accum_words, ncclUint64, ncclSum, c->comm, c->stream)
+		                          : rccl->Reduce(c->accum, c->accum, (size_t)c->accum_words, ncclUint64, ncclSum, root, c->comm, c->stream);
+		if (r != ncclSuccess) return fail(c, RTHIP_ERR_HIP, std::string(root < 0 ? "ncclAllReduce: " : "ncclReduce: ") + rccl->GetErrorString(r));
+		return RTHIP_OK;
+	});
+}
+
+int32_t rthip_merge_local(rthip_ctx* const* ctxs, int32_t n, int32_t root) {
+	if (!ctxs || n < 1 || root < 0 || root >= n || !ctxs[root]) return fail(nullptr, RTHIP_ERR_INVALID, "bad context list or root");
+	rthip_ctx* dst = ctxs[root];
+	void* staging = nullptr;
+	int32_t rc = guarded(dst, [&]() -> int32_t {
+		if (!dst->has_camera) return fail(dst, RTHIP_ERR_STATE, "set a camera first");
+		HIP_TRY(dst, hipSetDevice(dst->device));
+		int32_t rc = ensure_accum(dst);
+		if (rc != RTHIP_OK) return rc;
+		for (int32_t k = 0; k < n; k++) {
+			rthip_ctx* src = ctxs[k];
+			if (k == root) continue;
+			if (!src || !src->has_camera) return fail(dst, RTHIP_ERR_STATE, "a context of the list has no camera");
+			HIP_TRY(dst, hipSetDevice(src->device));
+			if ((rc = ensure_accum(src)) != RTHIP_OK) return fail(dst, rc, src->err);
+			if (src->accum_words != dst->accum_words) return fail(dst, RTHIP_ERR_INVALID, "the contexts render frames of different sizes");
+			if (src->accum == dst->accum) return fail(dst, RTHIP_ERR_INVALID, "two contexts of the list share one accumulation buffer");
+			HIP_TRY(dst, hipStreamSynchronize(src->stream));  // its renders are done before another stream reads them
+			HIP_TRY(dst, hipSetDevice(dst->device));
+			const unsigned long long* from = src->accum;
+			if (src->device != dst->device) {  // over xGMI into a staging buffer on the root's GPU
+				if (!staging) HIP_TRY(dst, hipMalloc(&staging, dst->accum_words * 8));
+				HIP_TRY(dst, hipMemcpyPeerAsync(staging, dst->device, src->accum, src->device, dst->accum_words * 8, dst->stream));
+				from = static_cast<const unsigned long long*>(staging);
+			}
+			HIP_TRY(dst, launch_add_words(dst->accum, from, dst->accum_words, dst->stream));
+		}
+		HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+		return RTHIP_OK;
+	});
+	if (staging) { (void)hipSetDevice(dst->device); (void)hipStreamSynchronize(dst->stream); (void)hipFree(staging); }
+	return rc;
 }
 
 int32_t rthip_accum_buffer(rthip_ctx* c, void** device_ptr, uint64_t* n_words) {

@@ -1,4 +1,5 @@
 // kernels_f32.hip — production instantiation: f32 VALU arithmetic, fp contraction allowed.
+#include <algorithm>
 #include <mutex>
 
 #include "launch.hpp"
@@ -44,6 +45,29 @@ hipError_t launch_finalize(const unsigned long long* accum, void* out, int width
 
 hipError_t wf_extend_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks) { return wf_extend_blocks_per_cu_impl(threads, scene_in_lds, dyn_lds, blocks); }
 hipError_t render_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks, bool quantised) { return blocks_per_cu_impl(threads, scene_in_lds, dyn_lds, blocks, quantised); }
+
+// Streams both buffers once: 24 bytes of HBM traffic per word, two words per thread and trip.
+__global__ __launch_bounds__(256) void add_words_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, uint64_t n) {
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	const uint64_t pairs = n / 2;
+	ulonglong2* d2 = reinterpret_cast<ulonglong2*>(dst);
+	const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(src);
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+		ulonglong2 a = d2[i];
+		const ulonglong2 b = s2[i];
+		a.x += b.x; a.y += b.y;
+		d2[i] = a;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) dst[n - 1] += src[n - 1];
+}
+hipError_t launch_add_words(unsigned long long* dst, const unsigned long long* src, uint64_t n, hipStream_t s) {
+	if (n == 0) return hipSuccess;
+	const bool aligned = (reinterpret_cast<uintptr_t>(dst) % 16 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+	if (!aligned) return hipErrorInvalidValue;  // accumulation buffers come from hipMalloc or a tensor allocator: 256-byte aligned
+	const unsigned grid = (unsigned)std::min<uint64_t>((n / 2 + 255) / 256 + 1, 256u * 8u);
+	hipLaunchKernelGGL(add_words_kernel, dim3(grid), dim3(256), 0, s, dst, src, n);
+	return hipGetLastError();
+}
 
 // Static scratch (see launch.hpp).  In host code the array's name is only a handle for
 // hipGetSymbolAddress; kernels and memsets get the per-device address looked up here.

@@ -31,6 +31,9 @@ hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width
 hipError_t launch_finalize(const unsigned long long* accum, void* out, int width, int height, int tiles_x, unsigned spp, int xrgb, hipStream_t s);
 
 
+// dst[i] += src[i] over n 64-bit words (the merge of two accumulation buffers on one GPU).
+hipError_t launch_add_words(unsigned long long* dst, const unsigned long long* src, uint64_t n, hipStream_t s);
+
 // A small array in static device memory (file scope of kernels_f32.hip), for the entry point that
 // must not allocate: it holds the control block of a launch (statistics and work-queue
 // counters), which every other entry point keeps in memory allocated at rthip_create.  Each GPU
