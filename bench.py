@@ -2,10 +2,13 @@
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torch.distributed.run)
 
-A step = one pass of the hot path: render `spp` samples of every pixel of the workload's frame
-into an accumulation buffer resident in HBM (and, for N > 1, merge the ranks' buffers with one
-RCCL reduce per frame, double-buffered so that it overlaps the next frame's tracing).  Scaling is weak: every GPU renders its own `spp` samples of the full frame, so
-N GPUs deliver an image of N x spp samples in the same time.  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over the workload: render the workload's `spp` samples of every
+pixel of its frame into an accumulation buffer resident in HBM.  With N > 1 GPUs the step's fixed
+sample budget is cut into N slices (strong scaling: rank r renders samples [r*spp/N, (r+1)*spp/N) of
+the full frame, `--split tile` cuts the 8x8 tiles instead), and ONE RCCL reduce of 64-bit integer
+words per step merges the ranks' buffers; it runs on a communication stream and overlaps the next
+step's tracing (two buffers in turn).  `--scaling weak` gives every GPU the whole budget instead.
+Rank 0 prints ONE JSON line.  The CPU legs (rank 0, N = 1) use the oracle as a measuring stick only.
 """
 import argparse
 import json
@@ -27,6 +30,8 @@ SCENE_SEED = 0x5EED0001
 RENDER_SEED = 0x5EED0001
 HEADLESS_CAMERA = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)  # raytracer_headless/src/main.rs:20-28
 PEAK_FP32_VALU_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
 
 def _wallpaper_camera():
     return ((0.0, 0.0, 0.0), rt.get_camera_rotation(-90.0, 0.0), 90.0, 10.0, 0.6)   # raytracer_gpu/src/main.rs:70
@@ -57,31 +62,38 @@ def host_threads():
     return os.cpu_count() or 1
 
 
-def cpu_side(scene, wl, run_baseline):
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_side(scene, wl, run_baseline, name):
     """Oracle legs (rank 0, N = 1 only): algorithmic work per path from a TIGHT-mode count on a
-    reduced frame of the same view, and the reference algorithm (FAITHFUL) timed on a bounded
-    sample of the workload."""
+    reduced frame of the same view; the reference algorithm (FAITHFUL) timed on a bounded sample of
+    the workload; and the minimal standard algorithm (TIGHT: true slab test, ordered, culled) timed on
+    the same sample, so that a speed-up splits into "better traversal" x "MI355X"."""
     from oracle import binding as ob  # measurement only: never on the product path
-    print("[bench] oracle: building the reference tree and counting algorithmic work", file=sys.stderr, flush=True)
+    log(f"{name}: oracle builds the reference tree and counts algorithmic work")
     osc = ob.OracleScene(scene.objects)
     camera = wl["camera"]()
     shrink = 8 if len(scene) < 100000 else 32   # the million-object scene: count work on a 240x135 frame
     cam_small = ob.camera_desc(*camera, wl["width"] // shrink, wl["height"] // shrink)
     _, _, cnt, _ = osc.render(cam_small, 4 if shrink == 8 else 1, wl["depth"], RENDER_SEED, ob.TIGHT, sky_mode=wl["sky"], threads=host_threads())
+    trav_flop = (15 * cnt["box_tests"] + 30 * cnt["sphere_tests"] + 25 * cnt["cube_tests"]) / cnt["paths"]
     work = dict(flop_per_path=ob.algorithmic_flops(cnt) / cnt["paths"], bytes_per_path=ob.algorithmic_bytes(cnt) / cnt["paths"],
-                rays_per_path=cnt["rays"] / cnt["paths"], box_tests_per_ray=cnt["box_tests"] / cnt["rays"],
-                prim_tests_per_ray=(cnt["sphere_tests"] + cnt["cube_tests"]) / cnt["rays"])
-    baseline = None
+                traversal_flop_per_path=trav_flop, rays_per_path=cnt["rays"] / cnt["paths"], box_tests_per_ray=cnt["box_tests"] / cnt["rays"],
+                prim_tests_per_ray=(cnt["sphere_tests"] + cnt["cube_tests"]) / cnt["rays"],
+                hits_per_path=(cnt["rays"] - cnt["sky_misses"]) / cnt["paths"])
+    baseline = tight = None
     if run_baseline:
         threads = host_threads()
         W, Hh = wl["width"], wl["height"]
         cam_full = ob.camera_desc(*camera, W, Hh)
-        print(f"[bench] cpu baseline: probing the reference algorithm on {threads} threads", file=sys.stderr, flush=True)
+        log(f"{name}: cpu baseline probes the reference algorithm on {threads} threads")
         if shrink == 8:
-            # size the sample to ~15 s of CPU work from a quick probe: whole frames when they are
+            # size the sample to ~12 s of CPU work from a quick probe: whole frames when they are
             # cheap enough (spp >= 1), else a centred band of rows at 1 spp
             _, _, c0, s0 = osc.render(cam_small, 2, wl["depth"], RENDER_SEED, ob.FAITHFUL, sky_mode=wl["sky"], threads=threads)
-            budget_paths = 15.0 * c0["paths"] / s0
+            budget_paths = 12.0 * c0["paths"] / s0
             frame = W * Hh
             if budget_paths >= frame:
                 spp, win = int(min(wl["spp"], budget_paths // frame)), (0, 0, W, Hh)
@@ -91,23 +103,43 @@ def cpu_side(scene, wl, run_baseline):
         else:
             # The reference's walk tests nearly every primitive of a million-object scene per ray
             # (~20 ms per ray): time a centred crop of the full-resolution frame, one row per thread
-            # at least, sized from a probe to ~20 s.
+            # at least, sized from a probe to ~15 s.
             x0, y0 = W // 2 - 8, Hh // 2 - threads // 2
             _, _, c0, s0 = osc.render(cam_full, 1, wl["depth"], RENDER_SEED, ob.FAITHFUL, sky_mode=wl["sky"], threads=threads,
                                       window=(x0, y0, x0 + 16, y0 + threads))
             per_path = s0 * threads / c0["paths"]                     # thread-seconds per path
-            cols = int(max(16, min(128, 20.0 * threads / per_path / 72)))
-            rows = int(max(threads, min(72, 20.0 * threads / per_path / cols)))
+            cols = int(max(16, min(128, 15.0 * threads / per_path / 72)))
+            rows = int(max(threads, min(72, 15.0 * threads / per_path / cols)))
             x0, y0 = (W - cols) // 2, (Hh - rows) // 2
             spp, win = 1, (x0, y0, x0 + cols, y0 + rows)
-        print(f"[bench] cpu baseline: timing window {win}, {spp} spp", file=sys.stderr, flush=True)
+        log(f"{name}: cpu baseline times window {win}, {spp} spp")
         _, _, c1, s1 = osc.render(cam_full, spp, wl["depth"], RENDER_SEED, ob.FAITHFUL, sky_mode=wl["sky"], threads=threads, window=win)
+        sample = f"pixels x {win[0]}..{win[2]}, y {win[1]}..{win[3]} of the {W}x{Hh} frame, {spp} spp, depth {wl['depth']}"
         baseline = dict(value=c1["paths"] / s1 / 1e6, unit="Mpaths/s", cores=threads, kind="port",
-                        sample=f"pixels x {win[0]}..{win[2]}, y {win[1]}..{win[3]} of the {W}x{Hh} frame, {spp} spp, depth {wl['depth']}: "
-                               f"{c1['paths']} paths in {s1:.1f} s; f64 restatement of the reference algorithm "
+                        sample=f"{sample}: {c1['paths']} paths in {s1:.1f} s; f64 restatement of the reference algorithm "
                                f"(recursive both-children BVH walk, per-axis AABB test), row-parallel on {threads} threads",
                         mrays_per_s=c1["rays"] / s1 / 1e6)
-    return work, baseline
+        # the algorithm-matched figure on the same window; repeated until it has run for a second or so
+        reps, secs, paths = 0, 0.0, 0
+        while secs < 1.0 and reps < 64:
+            _, _, c2, s2 = osc.render(cam_full, spp, wl["depth"], RENDER_SEED, ob.TIGHT, sky_mode=wl["sky"], threads=threads, window=win)
+            reps, secs, paths = reps + 1, secs + s2, paths + c2["paths"]
+        tight = dict(value=paths / secs / 1e6, unit="Mpaths/s", cores=threads, kind="port",
+                     sample=f"{sample}, {reps} pass(es): {paths} paths in {secs:.2f} s; the same paths by the minimal standard algorithm "
+                            f"(true slab test, near child first, culled by the best hit) on the reference-shaped tree")
+    return work, baseline, tight
+
+
+def measured_traffic(name):
+    """HBM bytes per path from rocprofv3 counters (FETCH_SIZE + WRITE_SIZE, corrected as the
+    microarchitecture guide prescribes), measured per round by tools/profile.sh."""
+    for rel in ("profiles/r02/traffic.json", "profiles/traffic.json"):
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            t = json.load(open(path)).get(name)
+            if t:
+                return t["hbm_bytes_per_path"], rel
+    return None, None
 
 
 def main():
@@ -116,12 +148,16 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per GPU per step")
+    ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel per step")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the step's fixed budget is split over the GPUs (default); weak = every GPU renders the whole budget")
     ap.add_argument("--split", default="spp", choices=["spp", "tile"],
-                    help="N > 1: spp = every GPU renders its own samples of the full frame (weak scaling, the default); "
-                         "tile = every GPU renders all samples of its own 8x8 tiles (strong scaling)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 / 1-spp frame extras")
+                    help="N > 1, strong scaling: spp = every GPU renders its slice of the samples of the full frame; "
+                         "tile = every GPU renders all samples of its own 8x8 tiles")
+    ap.add_argument("--merge", default="abi", choices=["abi", "torch"],
+                    help="N > 1: abi = rthip_merge_reduce (ncclReduce through the C ABI), falling back to torch.distributed.reduce")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other configs, the f64 rate and the 1-spp frame")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,27 +173,49 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    weak = args.scaling == "weak" and world > 1
+    tile_split = args.split == "tile" and world > 1 and not weak
 
-    def run_workload(name, steps, warmup, spp_override=0):
+    def share(spp):
+        """(spp_begin, spp_count, tile part) of this rank for a step of `spp` samples."""
+        if world == 1:
+            return 0, spp, (0, 1)
+        if weak:
+            return rank * spp, spp, (0, 1)
+        if tile_split:
+            return 0, spp, D.tile_part(rank, world)
+        begin, count = D.spp_slice(spp, rank, world)
+        return begin, count, (0, 1)
+
+    merge_kind = {"kind": "none"}
+
+    def make_pipeline(r, width, height):
+        make = lambda: D.new_accum_tensor(width, height, device)  # noqa: E731
+        if world > 1 and args.merge == "abi" and D.init_abi_comm(r, rank, world, device):
+            merge_kind["kind"] = "rthip_merge_reduce: ncclReduce(sum, uint64) through the C ABI, on a communication stream"
+            return D.AbiMergePipeline(r, make, root=0)
+        if world > 1:
+            merge_kind["kind"] = "torch.distributed.reduce(SUM, int64) over RCCL"
+        return D.MergePipeline(make, dst=0)
+
+    def run_workload(name, steps, warmup, spp_override=0, precision=rt.F32):
         wl = dict(WORKLOADS[name])
         if spp_override:
             wl["spp"] = spp_override
         scene = rt.Scene.generate(wl["scene"], SCENE_SEED)
         cam = rt.Camera(*wl["camera"](), wl["width"], wl["height"])
-        r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"])
+        r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"], precision=precision)
         stream = torch.cuda.current_stream(device)
         r.set_stream(stream.cuda_stream)
-        pipe = D.MergePipeline(lambda: D.new_accum_tensor(wl["width"], wl["height"], device), dst=0)
-        tile_split = args.split == "tile" and world > 1
-        begin = 0 if tile_split else rank * wl["spp"]  # spp split: every rank renders its own samples of the full frame
-        part = D.tile_part(rank, world) if tile_split else (0, 1)
+        pipe = make_pipeline(r, wl["width"], wl["height"])
+        begin, count, part = share(wl["spp"])
 
         def step():
             accum = pipe.acquire()   # the other buffer may still be in its reduce
             accum.zero_()
             r.set_accum_buffer(accum.data_ptr(), accum.numel())
-            r.accumulate(wl["spp"], part=part, spp_begin=begin, sync=False)
-            pipe.release()           # one RCCL reduce per frame, overlapped with the next frame's tracing
+            r.accumulate(count, part=part, spp_begin=begin, sync=False)
+            pipe.release()           # one RCCL reduce per step, overlapped with the next step's tracing
 
         for _ in range(warmup):
             step()
@@ -170,7 +228,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-            if rank == 0:
+            if rank == 0 and world == 1:
                 s = r.stats()  # waits for this step's kernel (HIP events on the launch stream)
                 kernel_ms.append(s["kernel_ms"]); rays, paths = s["rays"], s["paths"]
         pipe.drain()
@@ -178,14 +236,34 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        stats = r.stats()
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        out = dict(wl=wl, scene=scene, elapsed=elapsed, kernel_ms=float(np.mean(kernel_ms)) if kernel_ms else 0.0,
-                   rays=rays, paths=paths, stats=r.stats() if rank == 0 else None)
+            c = torch.tensor([stats["rays"], stats["paths"]], dtype=torch.int64, device=device)   # of every rank's last step
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            rays, paths = int(c[0].item()), int(c[1].item())
+        out = dict(wl=wl, scene=scene, elapsed=elapsed, kernel_ms=float(np.mean(kernel_ms)) if kernel_ms else stats["kernel_ms"],
+                   rays=rays, paths=paths, stats=stats)
+        if rank == 0 and world == 1 and precision == rt.F32 and not args.no_extra:
+            # executed work: box and primitive tests the kernel really ran, on the tree it really walks
+            r.set_option("count", 1)
+            r.set_accum_buffer(0, 0)
+            r.reset_accumulation()
+            r.accumulate(min(4, wl["spp"]), spp_begin=0)
+            s = r.stats()
+            out["executed"] = dict(box_tests_per_ray=s["box_tests"] / max(1, s["rays"]),
+                                   prim_tests_per_ray=(s["sphere_tests"] + s["cube_tests"]) / max(1, s["rays"]),
+                                   traversal_flop_per_path=(15 * s["box_tests"] + 30 * s["sphere_tests"] + 25 * s["cube_tests"]) / max(1, s["paths"]),
+                                   # a visit of a node reads it whole (two child boxes: 64 bytes, quantised 32), a primitive test 32 bytes, a hit its 16-byte material
+                                   node_bytes=32 if (not s["scene_in_lds"] and s["n_nodes"] > 2048) else 64,
+                                   node_visits_per_path=s["box_tests"] / 2 / max(1, s["paths"]),
+                                   prim_tests_per_path=(s["sphere_tests"] + s["cube_tests"]) / max(1, s["paths"]))
+            r.set_option("count", 0)
         # the 1-spp progressive frame (raytracer_runtime-style caller): ms per frame
-        if rank == 0 and name == "cfg2" and not args.no_extra and world == 1:
+        if rank == 0 and name == "cfg2" and not args.no_extra and world == 1 and precision == rt.F32:
+            r.set_accum_buffer(0, 0)
             r.reset_accumulation()
             for _ in range(3):
                 r.accumulate(1)
@@ -198,79 +276,133 @@ def main():
         r.close()
         return out
 
+    def self_check():
+        """N > 1: a small frame rendered in shares and merged must equal rank 0's own render of all
+        of it, bit for bit."""
+        wl = WORKLOADS[args.workload]
+        w, h, spp = 256, 144, 8
+        scene = rt.Scene.generate(wl["scene"] if len(wl["scene"]) < 12 else "default", SCENE_SEED)
+        cam = rt.Camera(*wl["camera"](), w, h)
+        r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"])
+        r.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        pipe = make_pipeline(r, w, h)
+        begin, count, part = (rank * spp, spp, (0, 1)) if weak else share(spp)
+        buf = pipe.acquire()
+        buf.zero_()
+        r.set_accum_buffer(buf.data_ptr(), buf.numel())
+        r.accumulate(count, part=part, spp_begin=begin, sync=False)
+        pipe.release()
+        pipe.drain()
+        torch.cuda.synchronize(device)
+        ok = True
+        if rank == 0:
+            merged = buf.clone()
+            own = D.new_accum_tensor(w, h, device)
+            r.set_accum_buffer(own.data_ptr(), own.numel())
+            r.accumulate(spp * world if weak else spp, spp_begin=0)
+            torch.cuda.synchronize(device)
+            ok = bool(torch.equal(own, merged))
+        r.close()
+        return ok
+
+    check = None
+    if world > 1:
+        check = self_check()
     res = run_workload(args.workload, args.steps, args.warmup, args.spp)
     wl = res["wl"]
-    tile_split = args.split == "tile" and world > 1
-    paths_per_step_all = wl["width"] * wl["height"] * wl["spp"] * (1 if tile_split else world)
+    paths_per_step_all = wl["width"] * wl["height"] * wl["spp"] * (world if weak else 1)
     value = paths_per_step_all * args.steps / res["elapsed"] / 1e6
 
     if rank == 0:
+        split_text = ("whole budget per GPU (weak scaling: N GPUs render N x spp samples)" if weak else
+                      "tile (each GPU renders all samples of its own 8x8 tiles)" if tile_split else
+                      "spp (each GPU renders its slice of the step's samples of the full frame)")
         line = {
             "metric": "Mpaths/s (path-tracing throughput, 1080p)", "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["elapsed"] / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if tile_split else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["desc"], "spp_per_gpu_per_step": wl["spp"], "split": ("tile (each GPU renders all samples of its own 8x8 tiles; one RCCL reduce merges)" if tile_split else
-                                 "spp (each GPU renders its own samples of the full frame; one RCCL reduce merges)"),
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "spp_per_step": wl["spp"], "split": split_text, "merge": merge_kind["kind"],
                        "scene_objects": int(len(res["scene"])), "tree_depth": res["stats"]["tree_depth"], "scene_in_lds": res["stats"]["scene_in_lds"]},
-            "mrays_per_s": res["rays"] * world * args.steps / res["elapsed"] / 1e6 if res["kernel_ms"] else None,  # rank 0's rays x ranks
+            # ray segments of the last step (summed over the ranks) per second of step time
+            "mrays_per_s": res["rays"] / (res["elapsed"] / args.steps) / 1e6,
             "rays_per_path": res["rays"] / max(1, res["paths"]),
         }
+        if check is not None:
+            line["merge_self_check"] = "bit-identical to one GPU (256x144, 8 spp)" if check else "MISMATCH"
         if "frame_ms_1spp" in res:
             line["frame_ms_1080p_1spp"] = res["frame_ms_1spp"]
-        work, baseline = (None, None)
-        if world == 1:
-            work, baseline = cpu_side(res["scene"], wl, not args.no_cpu)
-        if work:
-            flops_per_launch = work["flop_per_path"] * res["paths"]
-            achieved = flops_per_launch / (res["kernel_ms"] * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):  # measured with rocprofv3 counters (bytes per path), scaled to this launch
-                t = json.load(open(tpath)).get(args.workload)
-                traffic = t["hbm_bytes_per_path"] * res["paths"] if t else None
+
+        def rooflines(name, rs, work):
+            """The roofline objects of one workload from its run `rs` and the oracle's count `work`."""
+            wlx = rs["wl"]
+            secs = rs["kernel_ms"] * 1e-3
+            achieved = work["flop_per_path"] * rs["paths"] / secs / 1e12
+            per_path, src = measured_traffic(name)
+            traffic = per_path * rs["paths"] if per_path else None
             valu = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "kernel": "render_kernel<float>",
-                    "kernel_ms": res["kernel_ms"], "algorithmic_flop_per_path": work["flop_per_path"],
+                    "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "traffic_source": src, "kernel": "render_kernel<float>",
+                    "kernel_ms": rs["kernel_ms"], "algorithmic_flop_per_path": work["flop_per_path"],
                     "algorithmic_bytes_per_path": work["bytes_per_path"], "box_tests_per_ray": work["box_tests_per_ray"],
                     "prim_tests_per_ray": work["prim_tests_per_ray"]}
-            line["roofline"] = valu
-            if wl["bound"] == "hbm":
-                # Scene in global memory: every node and primitive record a ray reads comes through L1/L2.
-                # The algorithmic bytes (oracle TIGHT counts on the reference-shaped tree) over time
-                # exceed the HBM roof whenever caches serve most of them; `traffic` is what actually
-                # missed L2 (rocprofv3 FETCH_SIZE + WRITE_SIZE), the figure to hold against 8 TB/s.
-                gbs = work["bytes_per_path"] * res["paths"] / (res["kernel_ms"] * 1e-3) / 1e9
-                line["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
-                                        "measured_l2_miss_gbs": (traffic / (res["kernel_ms"] * 1e-3) / 1e9) if traffic else None,
-                                        "kernel": "render_kernel<float> (scene in global memory)",
-                                        "note": "latency bound: 70 % of wave cycles wait on memory (profiles/r01/cfg5_pmc_summary.json)"}
-            # the same launch against the memory roof: what the algorithm must move through HBM is one
-            # read-modify-write of the accumulation words of every pixel (scene and ray state stay on chip)
-            hbm_alg = wl["width"] * wl["height"] * 3 * 8 * 2
-            gbs = hbm_alg / (res["kernel_ms"] * 1e-3) / 1e9
-            if wl["bound"] != "hbm":
-                line["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
-                                        "note": "not the binding roof: the kernel is VALU-issue bound"}
-        if baseline:
-            line["cpu_baseline"] = baseline
-            line["speedup_vs_cpu"] = value / baseline["value"]
+            ex = rs.get("executed")
+            if ex:
+                # the same yardstick with the traversal part replaced by what the kernel executed on its own tree
+                flop_exec = work["flop_per_path"] - work["traversal_flop_per_path"] + ex["traversal_flop_per_path"]
+                valu.update(frac_executed=flop_exec * rs["paths"] / secs / 1e12 / PEAK_FP32_VALU_TFLOPS, executed_flop_per_path=flop_exec,
+                            executed_box_tests_per_ray=ex["box_tests_per_ray"], executed_prim_tests_per_ray=ex["prim_tests_per_ray"])
+            out = {"roofline": valu}
+            hbm_alg = wlx["width"] * wlx["height"] * 3 * 8 * 2   # one read-modify-write of every accumulation word
+            if wlx["bound"] == "hbm" and ex:
+                # Scene in global memory: the bytes the walk asks of the memory system, counted on the tree
+                # the kernel walks (device tallies), against the HBM roof; `traffic` is what missed L2.
+                bytes_per_path = ex["node_visits_per_path"] * ex["node_bytes"] + ex["prim_tests_per_path"] * 32 + work["hits_per_path"] * 16
+                gbs = bytes_per_path * rs["paths"] / secs / 1e9
+                # What reached HBM (L2 misses, measured with rocprofv3 counters on this workload) is the figure
+                # to hold against the HBM roof; the requested bytes are mostly served by L1/L2 and may exceed it.
+                measured = (traffic / secs / 1e9) if traffic else None
+                out["roofline_hbm"] = {"bound": "hbm", "achieved": measured, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": (measured / PEAK_HBM_GBS) if measured else None,
+                                       "traffic": traffic, "traffic_source": src,
+                                       "requested_bytes_per_path": bytes_per_path, "requested_gbs": gbs,
+                                       "kernel": "render_kernel<float> (scene in global memory, quantised nodes)",
+                                       "note": "achieved = measured L2-miss bytes (FETCH_SIZE + WRITE_SIZE per path x paths) over kernel time; "
+                                               "requested = node visits x node size + primitive tests x 32 + hits x 16 on the tree the kernel walks, "
+                                               "served mostly by L1/L2 (the kernel is bound by the L1's request rate, not by HBM)"}
+            else:
+                gbs = hbm_alg / secs / 1e9
+                out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic,
+                                       "note": "not the binding roof: scene and ray state stay on chip, the kernel is VALU-issue bound"}
+            return out
+
+        if world == 1:
+            work, baseline, tight = cpu_side(res["scene"], wl, not args.no_cpu, args.workload)
+            line.update(rooflines(args.workload, res, work))
+            if baseline:
+                line["cpu_baseline"] = baseline
+                line["cpu_baseline_tight"] = tight
+                line["speedup_vs_cpu"] = value / baseline["value"]
+                line["speedup_vs_cpu_tight"] = value / tight["value"]
         if world == 1 and not args.no_extra and args.workload == "cfg2":
-            # the many-spheres-and-cubes target workload, measured in the same run
-            r3 = run_workload("cfg3", 2, 1)
-            w3 = r3["wl"]
-            v3 = w3["width"] * w3["height"] * w3["spp"] * 2 / r3["elapsed"] / 1e6
-            extra = {"workload": w3["desc"], "value": v3, "unit": "Mpaths/s", "ms_per_step": r3["elapsed"] / 2 * 1e3,
-                     "mrays_per_s": r3["rays"] * 2 / r3["elapsed"] / 1e6, "kernel_ms": r3["kernel_ms"]}
-            if not args.no_cpu:
-                work3, base3 = cpu_side(r3["scene"], w3, True)
-                ach3 = work3["flop_per_path"] * r3["paths"] / (r3["kernel_ms"] * 1e-3) / 1e12
-                extra.update(cpu_baseline=base3, speedup_vs_cpu=v3 / base3["value"],
-                             roofline={"bound": "valu_fp32", "achieved": ach3, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": ach3 / PEAK_FP32_VALU_TFLOPS, "algorithmic_flop_per_path": work3["flop_per_path"]})
-            line["cfg3"] = extra
-        print(json.dumps(line))
-    elif world == 1:
-        pass
+            # the reference's own arithmetic on the GPU (bit-exact parity mode), same workload at a tenth of the samples
+            r64 = run_workload("cfg2", 2, 1, 10, precision=rt.F64)
+            line["f64_mode"] = {"value": r64["wl"]["width"] * r64["wl"]["height"] * 10 * 2 / r64["elapsed"] / 1e6, "unit": "Mpaths/s",
+                                "kernel_ms": r64["kernel_ms"], "spp_per_step": 10, "dtype": "f64"}
+            # the other single-GPU configurations, measured in the same run (bounded: few steps each)
+            for name, steps in (("cfg3", 5), ("cfg4", 3), ("cfg5", 3)):
+                log(f"extra workload {name}")
+                rx = run_workload(name, steps, 1)
+                wx = rx["wl"]
+                vx = wx["width"] * wx["height"] * wx["spp"] * steps / rx["elapsed"] / 1e6
+                extra = {"workload": wx["desc"], "value": vx, "unit": "Mpaths/s", "steps": steps, "ms_per_step": rx["elapsed"] / steps * 1e3,
+                         "mrays_per_s": rx["rays"] / (rx["elapsed"] / steps) / 1e6, "rays_per_path": rx["rays"] / max(1, rx["paths"]),
+                         "kernel_ms": rx["kernel_ms"], "scene_in_lds": rx["stats"]["scene_in_lds"]}
+                workx, basex, tightx = cpu_side(rx["scene"], wx, not args.no_cpu, name)
+                extra.update(rooflines(name, rx, workx))
+                if basex:
+                    extra.update(cpu_baseline=basex, cpu_baseline_tight=tightx, speedup_vs_cpu=vx / basex["value"],
+                                 speedup_vs_cpu_tight=vx / tightx["value"])
+                line[name] = extra
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -174,13 +174,19 @@ int32_t rthip_accum_upload(rthip_ctx* ctx, const uint64_t* words, uint64_t n_wor
  * rank 0 makes an id with rthip_comm_unique_id and hands the 128 bytes to the others by any
  * means; every rank calls rthip_comm_init(ctx, id, rank, world) (collective: all ranks must be
  * in the call at once); rthip_merge_reduce then enqueues ONE ncclReduce(sum, uint64) of the
- * accumulation buffer, in place, on the context's stream, behind the renders already queued;
- * root = the rank that ends with the image, or -1 for all of them (all-reduce).  Integer sums:
- * the merged words equal a single GPU's, bit for bit.  librccl is looked up at the first call
- * (RTHIP_ERR_STATE when the host has none). */
+ * active accumulation buffer, in place, behind the renders already queued; root = the rank that
+ * ends with the image, or -1 for all of them (all-reduce).  Integer sums: the merged words equal
+ * a single GPU's, bit for bit.  The reduce runs on a communication stream of its own: a render
+ * queued afterwards into ANOTHER buffer (rthip_set_accum_buffer) overlaps it.  Whatever this
+ * library does next to the SAME buffer (render, reset, read-back, another reduce) waits for it
+ * first, and so does rthip_synchronize; a caller that touches the buffer itself (a memset on its
+ * own stream) calls rthip_merge_wait(ctx, buffer) before, which orders the context's stream
+ * behind the reduces in flight on that buffer (NULL: on any buffer).  librccl is looked up at
+ * the first call (RTHIP_ERR_STATE when the host has none). */
 int32_t rthip_comm_unique_id(uint8_t id[128]);
 int32_t rthip_comm_init(rthip_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t world);
 int32_t rthip_merge_reduce(rthip_ctx* ctx, int32_t root);
+int32_t rthip_merge_wait(rthip_ctx* ctx, const void* device_ptr);
 /* The same sum without RCCL, for contexts of ONE process called from one thread (several GPUs,
  * or several contexts on one GPU): adds the accumulation buffers of ctxs[0..n) into
  * ctxs[root]'s (peer copies over xGMI where the GPUs differ) and waits for the result. */

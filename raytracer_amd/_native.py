@@ -63,6 +63,7 @@ SYMBOLS = {
     "rthip_comm_unique_id": (C.c_int32, [_P]),
     "rthip_comm_init": (C.c_int32, [_P, _P, C.c_int32, C.c_int32]),
     "rthip_merge_reduce": (C.c_int32, [_P, C.c_int32]),
+    "rthip_merge_wait": (C.c_int32, [_P, _P]),
     "rthip_merge_local": (C.c_int32, [C.POINTER(_P), C.c_int32, C.c_int32]),
     "rthip_accum_download": (C.c_int32, [_P, _P, C.c_uint64]),
     "rthip_accum_upload": (C.c_int32, [_P, _P, C.c_uint64]),

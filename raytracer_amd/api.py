@@ -283,6 +283,10 @@ class Renderer:
         place, enqueued behind the renders on this context's stream."""
         self._check(self._lib.rthip_merge_reduce(self._ctx, int(root)))
 
+    def merge_wait(self, device_ptr=0):
+        """Orders this context's stream behind the reduces in flight on that buffer (0: any)."""
+        self._check(self._lib.rthip_merge_wait(self._ctx, C.c_void_p(device_ptr)))
+
     def save_checkpoint(self, path):
         """Writes the accumulation words and the sample count to an .npz file; load_checkpoint on a
         renderer of the same scene, camera and seed resumes the render where it stopped (sums are

@@ -110,6 +110,12 @@ struct rthip_ctx {
 	bool last_in_lds = false;
 	ncclComm_t comm = nullptr;  // this context's rank in a communicator of GPUs (rthip_comm_init)
 	int comm_rank = -1, comm_world = 0;
+	// Reduces run on a stream of their own, so that the next frame's tracing (into another buffer)
+	// overlaps them.  Each one in flight is remembered by the buffer it works on: whatever this
+	// library does next to that buffer first makes the render stream wait for it.
+	hipStream_t comm_stream = nullptr;
+	struct PendingMerge { void* buf = nullptr; hipEvent_t ready = nullptr, done = nullptr; bool active = false; };
+	PendingMerge merges[4];
 };
 
 namespace {
@@ -411,11 +417,21 @@ int32_t collect_stats(rthip_ctx* c) {
 	return RTHIP_OK;
 }
 
+// Orders the render stream behind the reduces in flight on `buf` (all of them when buf is null).
+int32_t wait_merges(rthip_ctx* c, const void* buf) {
+	for (auto& m : c->merges) {
+		if (!m.active || (buf && m.buf != buf)) continue;
+		HIP_TRY(c, hipStreamWaitEvent(c->stream, m.done, 0));
+		m.active = false;
+	}
+	return RTHIP_OK;
+}
+
 int32_t ensure_accum(rthip_ctx* c) {
 	uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
 	if (c->accum && c->accum != c->own_accum) {
 		if (c->accum_words != words) return fail(c, RTHIP_ERR_STATE, "caller-owned accumulation buffer does not match the image size");
-		return RTHIP_OK;
+		return wait_merges(c, c->accum);
 	}
 	if (c->own_words != words) {
 		if (c->own_accum) { HIP_TRY(c, hipFree(c->own_accum)); c->own_accum = nullptr; c->own_words = 0; }
@@ -424,7 +440,7 @@ int32_t ensure_accum(rthip_ctx* c) {
 		HIP_TRY(c, hipMemsetAsync(c->own_accum, 0, words * 8, c->stream));
 	}
 	c->accum = c->own_accum; c->accum_words = words;
-	return RTHIP_OK;
+	return wait_merges(c, c->accum);
 }
 
 }  // namespace
@@ -477,9 +493,15 @@ void rthip_destroy(rthip_ctx* c) {
 		(void)hipSetDevice(c->device);
 		if (c->stream) (void)hipStreamSynchronize(c->stream);
 		if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
+		if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
 		if (c->comm) {
 			if (const RcclApi* rccl = RcclApi::get(nullptr)) (void)rccl->CommDestroy(c->comm);
 		}
+		for (auto& m : c->merges) {
+			if (m.ready) (void)hipEventDestroy(m.ready);
+			if (m.done) (void)hipEventDestroy(m.done);
+		}
+		if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
 		if (c->blob32.dev) (void)hipFree(c->blob32.dev);
 		if (c->blob64.dev) (void)hipFree(c->blob64.dev);
 		if (c->own_accum) (void)hipFree(c->own_accum);
@@ -651,6 +673,7 @@ int32_t rthip_synchronize(rthip_ctx* c) {
 		HIP_TRY(c, hipSetDevice(c->device));
 		int32_t rc = collect_stats(c);
 		if (rc != RTHIP_OK) return rc;
+		if ((rc = wait_merges(c, nullptr)) != RTHIP_OK) return rc;
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		return RTHIP_OK;
 	});
@@ -703,6 +726,11 @@ int32_t rthip_comm_init(rthip_ctx* c, const uint8_t id[128], int32_t rank, int32
 		ncclResult_t r = rccl->CommInitRank(&c->comm, world, u, rank);
 		if (r != ncclSuccess) { c->comm = nullptr; return fail(c, RTHIP_ERR_HIP, std::string("ncclCommInitRank: ") + rccl->GetErrorString(r)); }
 		c->comm_rank = rank; c->comm_world = world;
+		if (!c->comm_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+		for (auto& m : c->merges) {
+			if (!m.ready) HIP_TRY(c, hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
+			if (!m.done) HIP_TRY(c, hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
+		}
 		return RTHIP_OK;
 	});
 }
@@ -715,14 +743,30 @@ int32_t rthip_merge_reduce(rthip_ctx* c, int32_t root) {
 		if (!c->has_camera) return fail(c, RTHIP_ERR_STATE, "set a camera first");
 		const RcclApi* rccl = RcclApi::get(nullptr);
 		HIP_TRY(c, hipSetDevice(c->device));
-		int32_t rc = ensure_accum(c);
+		int32_t rc = ensure_accum(c);  // also orders this reduce behind an earlier one on the same buffer
 		if (rc != RTHIP_OK) return rc;
-		// In place, in stream order behind the renders that filled the buffer: sums of 64-bit integers
-		// are exact and independent of the order RCCL adds them in.
-		ncclResult_t r = root < 0 ? rccl->AllReduce(c->accum, c->accum, (size_t)c->accum_words, ncclUint64, ncclSum, c->comm, c->stream)
-		                          : rccl->Reduce(c->accum, c->accum, (size_t)c->accum_words, ncclUint64, ncclSum, root, c->comm, c->stream);
+		// a slot for this buffer: a free one, else the first (its reduce is waited for before the slot is reused)
+		rthip_ctx::PendingMerge* slot = nullptr;
+		for (auto& m : c->merges) if (!m.active) { slot = &m; break; }
+		if (!slot) { slot = &c->merges[0]; HIP_TRY(c, hipStreamWaitEvent(c->stream, slot->done, 0)); slot->active = false; }
+		// In place, behind the renders that filled the buffer, on the communication stream: sums of
+		// 64-bit integers are exact and independent of the order RCCL adds them in.
+		HIP_TRY(c, hipEventRecord(slot->ready, c->stream));
+		HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, slot->ready, 0));
+		ncclResult_t r = root < 0 ? rccl->AllReduce(c->accum, c->accum, (size_t)c->accum_words, ncclUint64, ncclSum, c->comm, c->comm_stream)
+		                          : rccl->Reduce(c->accum, c->accum, (size_t)c->accum_words, ncclUint64, ncclSum, root, c->comm, c->comm_stream);
 		if (r != ncclSuccess) return fail(c, RTHIP_ERR_HIP, std::string(root < 0 ? "ncclAllReduce: " : "ncclReduce: ") + rccl->GetErrorString(r));
+		HIP_TRY(c, hipEventRecord(slot->done, c->comm_stream));
+		slot->buf = c->accum; slot->active = true;
 		return RTHIP_OK;
+	});
+}
+
+int32_t rthip_merge_wait(rthip_ctx* c, const void* device_ptr) {
+	if (!c) return RTHIP_ERR_INVALID;
+	return guarded(c, [&]() -> int32_t {
+		HIP_TRY(c, hipSetDevice(c->device));
+		return wait_merges(c, device_ptr);
 	});
 }
 

@@ -85,6 +85,50 @@ class MergePipeline:
                 self.pending[i] = None
 
 
+def init_abi_comm(renderer, rank, world, device):
+    """Makes `renderer`'s context rank `rank` of an RCCL communicator of `world` GPUs through the C
+    ABI (rthip_comm_unique_id / rthip_comm_init).  The 128-byte id travels from rank 0 over the
+    torch.distributed group that is already up.  Returns True when every rank succeeded; on False
+    the caller merges through torch.distributed instead."""
+    ok = 1
+    try:
+        raw = renderer.comm_unique_id() if rank == 0 else bytes(128)
+        ident = torch.tensor(list(raw), dtype=torch.uint8, device=device)
+        dist.broadcast(ident, src=0)
+        renderer.comm_init(bytes(ident.cpu().tolist()), rank, world)
+    except Exception as e:  # no librccl, or RCCL refused: every rank learns of it below
+        print(f"[distributed] rank {rank}: C-ABI communicator not available ({e})", flush=True)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+class AbiMergePipeline:
+    """MergePipeline with the reduce behind the C ABI (rthip_merge_reduce: one ncclReduce of uint64
+    words on the context's communication stream).  The renderer's stream must be the stream the
+    caller zeroes the buffers on (Renderer.set_stream), so that acquire() orders both behind the
+    reduce that last used the buffer."""
+
+    def __init__(self, renderer, make_buffer, root=0):
+        self.r, self.root, self.k = renderer, root, 0
+        self.bufs = [make_buffer(), make_buffer()]
+
+    def acquire(self):
+        buf = self.bufs[self.k % 2]
+        self.r.merge_wait(buf.data_ptr())
+        return buf
+
+    def release(self):
+        buf = self.bufs[self.k % 2]
+        self.r.merge_reduce(self.root)     # of the renderer's active buffer: the one acquire() handed out
+        self.k += 1
+        return buf
+
+    def drain(self):
+        self.r.merge_wait(0)
+
+
 def accum_to_image(accum, width, height):
     """Decode a (merged) accumulation buffer to sum_s sqrt(sample), float64 [H, W, 3], on the host."""
     words = accum.detach().cpu().numpy().view(np.uint64)
