@@ -156,9 +156,17 @@ def main():
                          "tile = every GPU renders all samples of its own 8x8 tiles")
     ap.add_argument("--merge", default="abi", choices=["abi", "torch"],
                     help="N > 1: abi = rthip_merge_reduce (ncclReduce through the C ABI), falling back to torch.distributed.reduce")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="run the N > 1 code path (process group, communicator, merge pipeline, self-check) with the ranks there are, even one")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the other configs, the f64 rate and the 1-spp frame")
     args = ap.parse_args()
+
+    # Libraries under this process write banners to stdout (RCCL prints its version block at the first
+    # communicator): everything but the one JSON line goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -170,15 +178,17 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.rehearse_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    weak = args.scaling == "weak" and world > 1
-    tile_split = args.split == "tile" and world > 1 and not weak
+    weak = args.scaling == "weak" and multi
+    tile_split = args.split == "tile" and multi and not weak
 
     def share(spp):
         """(spp_begin, spp_count, tile part) of this rank for a step of `spp` samples."""
-        if world == 1:
+        if not multi:
             return 0, spp, (0, 1)
         if weak:
             return rank * spp, spp, (0, 1)
@@ -191,10 +201,10 @@ def main():
 
     def make_pipeline(r, width, height):
         make = lambda: D.new_accum_tensor(width, height, device)  # noqa: E731
-        if world > 1 and args.merge == "abi" and D.init_abi_comm(r, rank, world, device):
+        if multi and args.merge == "abi" and D.init_abi_comm(r, rank, world, device):
             merge_kind["kind"] = "rthip_merge_reduce: ncclReduce(sum, uint64) through the C ABI, on a communication stream"
             return D.AbiMergePipeline(r, make, root=0)
-        if world > 1:
+        if multi:
             merge_kind["kind"] = "torch.distributed.reduce(SUM, int64) over RCCL"
         return D.MergePipeline(make, dst=0)
 
@@ -222,22 +232,22 @@ def main():
         pipe.drain()
         kernel_ms = []
         rays = paths = 0
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-            if rank == 0 and world == 1:
+            if rank == 0 and not multi:
                 s = r.stats()  # waits for this step's kernel (HIP events on the launch stream)
                 kernel_ms.append(s["kernel_ms"]); rays, paths = s["rays"], s["paths"]
         pipe.drain()
         torch.cuda.synchronize(device)
-        if world > 1:
+        if multi:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         stats = r.stats()
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -246,7 +256,7 @@ def main():
             rays, paths = int(c[0].item()), int(c[1].item())
         out = dict(wl=wl, scene=scene, elapsed=elapsed, kernel_ms=float(np.mean(kernel_ms)) if kernel_ms else stats["kernel_ms"],
                    rays=rays, paths=paths, stats=stats)
-        if rank == 0 and world == 1 and precision == rt.F32 and not args.no_extra:
+        if rank == 0 and not multi and precision == rt.F32 and not args.no_extra:
             # executed work: box and primitive tests the kernel really ran, on the tree it really walks
             r.set_option("count", 1)
             r.set_accum_buffer(0, 0)
@@ -262,7 +272,7 @@ def main():
                                    prim_tests_per_path=(s["sphere_tests"] + s["cube_tests"]) / max(1, s["paths"]))
             r.set_option("count", 0)
         # the 1-spp progressive frame (raytracer_runtime-style caller): ms per frame
-        if rank == 0 and name == "cfg2" and not args.no_extra and world == 1 and precision == rt.F32:
+        if rank == 0 and name == "cfg2" and not args.no_extra and not multi and precision == rt.F32:
             r.set_accum_buffer(0, 0)
             r.reset_accumulation()
             for _ in range(3):
@@ -306,7 +316,7 @@ def main():
         return ok
 
     check = None
-    if world > 1:
+    if multi:
         check = self_check()
     res = run_workload(args.workload, args.steps, args.warmup, args.spp)
     wl = res["wl"]
@@ -374,7 +384,7 @@ def main():
                                        "note": "not the binding roof: scene and ray state stay on chip, the kernel is VALU-issue bound"}
             return out
 
-        if world == 1:
+        if not multi:
             work, baseline, tight = cpu_side(res["scene"], wl, not args.no_cpu, args.workload)
             line.update(rooflines(args.workload, res, work))
             if baseline:
@@ -382,7 +392,7 @@ def main():
                 line["cpu_baseline_tight"] = tight
                 line["speedup_vs_cpu"] = value / baseline["value"]
                 line["speedup_vs_cpu_tight"] = value / tight["value"]
-        if world == 1 and not args.no_extra and args.workload == "cfg2":
+        if not multi and not args.no_extra and args.workload == "cfg2":
             # the reference's own arithmetic on the GPU (bit-exact parity mode), same workload at a tenth of the samples
             r64 = run_workload("cfg2", 2, 1, 10, precision=rt.F64)
             line["f64_mode"] = {"value": r64["wl"]["width"] * r64["wl"]["height"] * 10 * 2 / r64["elapsed"] / 1e6, "unit": "Mpaths/s",
@@ -402,8 +412,9 @@ def main():
                     extra.update(cpu_baseline=basex, cpu_baseline_tight=tightx, speedup_vs_cpu=vx / basex["value"],
                                  speedup_vs_cpu_tight=vx / tightx["value"])
                 line[name] = extra
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
