@@ -27,6 +27,7 @@ struct SceneBlob {  // one precision of the scene in HBM: [nodes | prims | mats]
 	char* dev = nullptr;
 	uint32_t prims_off = 0, mats_off = 0, gates_off = 0, bytes = 0;
 	uint32_t lds_bytes = 0;  // nodes + prims + gates: what an LDS-resident launch copies
+	uint32_t lds_bytes_mats = 0;  // the same plus the materials, which follow them in the blob
 	uint32_t qnodes_off = 0; // quantised nodes behind the materials (f32 blob of a large scene), 0 = none
 	QFrame qframe{};
 };
@@ -43,6 +44,8 @@ int env_int(const char* name, int dflt) {
 struct Tuning {
 	int scene_lds = -1;       // RTHIP_SCENE_LDS: -1 = by size, 0 = never, 1 = whenever it fits 100 KB
 	int qnodes = 1;           // RTHIP_QNODES: traverse the quantised nodes of large f32 scenes
+	int mats_lds = 1;         // RTHIP_MATS_LDS: keep the materials in LDS too when that costs no resident wave
+	int acc_lds = -1;         // RTHIP_ACC_LDS: per-wave accumulation tiles in LDS: -1 = scenes with nothing below the root, 0 = never, 1 = wherever they fit
 	int threads = 0;          // RTHIP_THREADS: force the workgroup size (256, 512, 1024), 0 = most resident waves
 	int blocks_per_cu = 0;    // RTHIP_BLOCKS_PER_CU: cap on resident workgroups per CU, 0 = none
 	int chunk = 0;            // RTHIP_CHUNK: samples of a tile per work item, 0 = by launch size
@@ -57,6 +60,8 @@ struct Tuning {
 		Tuning t;
 		t.scene_lds = env_int("RTHIP_SCENE_LDS", t.scene_lds);
 		t.qnodes = env_int("RTHIP_QNODES", t.qnodes);
+		t.mats_lds = env_int("RTHIP_MATS_LDS", t.mats_lds);
+		t.acc_lds = env_int("RTHIP_ACC_LDS", t.acc_lds);
 		t.threads = env_int("RTHIP_THREADS", t.threads);
 		t.blocks_per_cu = env_int("RTHIP_BLOCKS_PER_CU", t.blocks_per_cu);
 		t.chunk = env_int("RTHIP_CHUNK", t.chunk);
@@ -98,7 +103,7 @@ struct rthip_ctx {
 	Tuning tune;
 	BuildOptions build_opt;
 	// resident workgroups per CU by (f64, wavefront, threads, scene in LDS, quantised, dynamic LDS bytes): asked of the runtime once
-	std::map<std::tuple<bool, bool, int, bool, bool, size_t>, int> occupancy;
+	std::map<std::tuple<bool, bool, int, int, bool, size_t>, int> occupancy;
 	// wavefront variant: ping-pong path state, hit records and the per-bounce counter block
 	char* wf_mem = nullptr;
 	size_t wf_bytes = 0;
@@ -180,6 +185,7 @@ int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const st
 	HIP_TRY(c, hipMemcpy(b->dev, host.data(), (size_t)total, hipMemcpyHostToDevice));
 	b->prims_off = (uint32_t)prims_off; b->mats_off = (uint32_t)mats_off; b->gates_off = (uint32_t)gates_off; b->bytes = (uint32_t)total;
 	b->lds_bytes = (uint32_t)mats_off;
+	b->lds_bytes_mats = align_up(mats_off + mb, 64);
 	return RTHIP_OK;
 }
 
@@ -210,13 +216,13 @@ int32_t validate(rthip_ctx* c, const rthip_render_params* p) {
 }
 
 // Resident workgroups per CU, asked of the runtime once per kernel variant and LDS size.
-int32_t blocks_per_cu(rthip_ctx* c, bool f64, bool wavefront, int threads, bool in_lds, bool quantised, size_t lds, int* out) {
-	const auto key = std::make_tuple(f64, wavefront, threads, in_lds, quantised, lds);
+int32_t blocks_per_cu(rthip_ctx* c, bool f64, bool wavefront, int threads, int lds_mode, bool quantised, size_t lds, int* out, bool acc_lds = false) {
+	const auto key = std::make_tuple(f64, wavefront, threads, lds_mode + (acc_lds ? 8 : 0), quantised, lds);
 	auto it = c->occupancy.find(key);
 	if (it != c->occupancy.end()) { *out = it->second; return RTHIP_OK; }
 	int b = 0;
-	if (wavefront) HIP_TRY(c, f64 ? wf_extend_blocks_per_cu_f64(threads, in_lds, lds, &b) : wf_extend_blocks_per_cu_f32(threads, in_lds, lds, &b));
-	else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, in_lds, lds, &b) : render_blocks_per_cu_f32(threads, in_lds, lds, &b, quantised));
+	if (wavefront) HIP_TRY(c, f64 ? wf_extend_blocks_per_cu_f64(threads, lds_mode != 0, lds, &b) : wf_extend_blocks_per_cu_f32(threads, lds_mode != 0, lds, &b));
+	else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, lds_mode, lds, &b) : render_blocks_per_cu_f32(threads, lds_mode, lds, &b, quantised, acc_lds));
 	c->occupancy[key] = b;
 	*out = b;
 	return RTHIP_OK;
@@ -227,27 +233,56 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	const SceneBlob& blob = f64 ? c->blob64 : c->blob32;
 	const Tuning& tune = c->tune;
 	bool in_lds = tune.scene_lds < 0 ? blob.lds_bytes <= kLdsSceneLimit : (tune.scene_lds != 0 && blob.lds_bytes <= 100 * 1024);
+	plan->cfg.device = c->device;
 	plan->cfg.scene_in_lds = in_lds;
 	plan->cfg.count = count;
 	plan->cfg.quantised = !in_lds && !f64 && !wavefront && blob.qnodes_off != 0 && tune.qnodes != 0;
-	// Workgroup size: the kernel is latency bound, so pick the size that keeps the most waves
-	// resident.  Every workgroup holds its own LDS copy of the scene, so larger workgroups
-	// amortise it.
+	// Workgroup size and LDS contents: the kernel is latency bound, so pick what keeps the most
+	// waves resident.  Every workgroup holds its own LDS copy of the scene, so larger workgroups
+	// amortise it; among equals, the one that has room for the materials too wins (tried first).
 	const int forced = tune.threads;
 	int best_waves = -1, bpc = 0;
-	for (int threads : {256, 512, 1024}) {
-		if (forced && threads != forced) continue;
-		if (threads == 1024 && (wavefront || forced != 1024)) continue;  // 32 waves per CU at 64 VGPRs measured no faster than 24 at 80: on request only
-		size_t lds = (size_t)c->tree_depth * threads * 4 + (in_lds ? blob.lds_bytes : 0);
-		int b = 0;
-		int32_t rc = blocks_per_cu(c, f64, wavefront, threads, in_lds, plan->cfg.quantised, lds, &b);
-		if (rc != RTHIP_OK) return rc;
-		if (b * threads / 64 > best_waves) {
-			best_waves = b * threads / 64; bpc = b;
-			plan->cfg.threads = threads; plan->cfg.dyn_lds = lds;
+	for (int lds_mode : {2, 1, 0}) {
+		if ((lds_mode != 0) != in_lds) continue;
+		if (lds_mode == 2 && (wavefront || tune.mats_lds == 0 || blob.lds_bytes_mats > kLdsSceneLimit)) continue;
+		for (int threads : {256, 512, 768, 1024}) {
+			if (forced && threads != forced) continue;
+			if (threads == 1024 && (wavefront || forced != 1024 || lds_mode == 2)) continue;  // 32 waves per CU at 64 VGPRs measured no faster than 24 at 80: on request only
+			if (threads == 768 && lds_mode != 2) continue;  // two workgroups of twelve waves: only built for the variant that needs the room
+			size_t lds = (size_t)c->tree_depth * threads * 4 + (lds_mode == 2 ? blob.lds_bytes_mats : lds_mode == 1 ? blob.lds_bytes : 0);
+			int b = 0;
+			int32_t rc = blocks_per_cu(c, f64, wavefront, threads, lds_mode, plan->cfg.quantised, lds, &b);
+			if (rc != RTHIP_OK) return rc;
+			if (b * threads / 64 > best_waves) {
+				best_waves = b * threads / 64; bpc = b;
+				plan->cfg.threads = threads; plan->cfg.dyn_lds = lds; plan->cfg.lds_mode = lds_mode;
+			}
 		}
 	}
 	if (bpc < 1) return fail(c, RTHIP_ERR_LIMIT, "render kernel does not fit on a CU");
+	// Scenes with nothing below the root (a few objects under an open sky: paths of 1.3 rays, two
+	// node visits each) are bound by the three accumulation atomics per path, not by arithmetic:
+	// there the waves sum their samples in LDS tiles and write a tile once per work item
+	// (kAccLds in kernels.hpp).  Recognised by the tree alone, so that a launch does not depend on
+	// the launches before it; only where the tiles cost no resident wave, and not for launches of a
+	// few samples, whose items are one wave's worth of paths anyway.
+	plan->cfg.acc_lds = false;
+	plan->cfg.acc_tile_off = 0;
+	const bool acc_wanted = tune.acc_lds > 0 || (tune.acc_lds < 0 && c->n_nodes <= 1);
+	if (acc_wanted && !f64 && !wavefront && !count && plan->cfg.lds_mode == 2 && p->spp_count >= 8) {
+		for (int threads : {256, 512}) {
+			if (forced && threads != forced) continue;
+			const size_t base = (size_t)c->tree_depth * threads * 4 + blob.lds_bytes_mats;
+			const size_t lds = base + (size_t)(threads / 64) * kTilePixels * kAccumChannels * 8;
+			int b = 0;
+			int32_t rc = blocks_per_cu(c, f64, wavefront, threads, 2, false, lds, &b, true);
+			if (rc != RTHIP_OK) return rc;
+			if (b * threads / 64 >= best_waves && (!plan->cfg.acc_lds || b * threads / 64 > best_waves)) {
+				best_waves = b * threads / 64; bpc = b;
+				plan->cfg.threads = threads; plan->cfg.dyn_lds = lds; plan->cfg.acc_lds = true; plan->cfg.acc_tile_off = (uint32_t)base;
+			}
+		}
+	}
 	const int cap = tune.blocks_per_cu;
 	if (cap > 0) bpc = std::min(bpc, cap);
 	uint64_t n_tiles = (uint64_t)c->tiles_x * c->tiles_y;
@@ -263,6 +298,9 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// three-object scene at any spp.  Recognised by the tree alone (nothing below the root), so
 	// that a launch does not depend on the launches before it.
 	if (c->n_nodes <= 1) auto_chunk = 32;
+	// With LDS tiles an item costs one flush and one drain of the wave: as many samples per item as
+	// divide the launch evenly, up to 64.
+	if (plan->cfg.acc_lds) auto_chunk = (p->spp_count + (p->spp_count + 63) / 64 - 1) / ((p->spp_count + 63) / 64);
 	uint32_t chunk = (uint32_t)std::max(1, tune.chunk > 0 ? tune.chunk : (int)auto_chunk);
 	chunk = std::min<uint32_t>(chunk, std::max<uint32_t>(1u, p->spp_count));
 	uint32_t n_chunks = (p->spp_count + chunk - 1) / chunk;
@@ -292,7 +330,8 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	RenderArgs<Real> a;
 	std::memset(&a, 0, sizeof(a));
 	a.scene = blob.dev; a.prims_off = blob.prims_off; a.mats_off = blob.mats_off; a.gates_off = blob.gates_off; a.scene_bytes = blob.bytes;
-	a.lds_bytes = blob.lds_bytes;
+	a.lds_bytes = plan.cfg.lds_mode == 2 ? blob.lds_bytes_mats : blob.lds_bytes;
+	a.acc_tile_off = plan.cfg.acc_tile_off;
 	a.qnodes_off = blob.qnodes_off; a.qframe = blob.qframe;
 	a.big_leaf = c->big_leaf; a.start = c->start;
 	a.stack_entries = c->tree_depth;
@@ -397,7 +436,7 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 int32_t collect_stats(rthip_ctx* c) {
 	if (!c->launch_pending) return RTHIP_OK;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	unsigned long long s[5 + 2 * kRegCount];
+	unsigned long long s[5 + 2 * kRegCount + kPhCount];
 	HIP_TRY(c, hipMemcpy(s, (c->last_control ? c->last_control : c->d_control) + 8, sizeof(s), hipMemcpyDeviceToHost));
 	if (!c->tune.region_dump.empty() && c->tune.count) {  // instrumented runs: lane utilisation per code region
 		static const char* names[kRegCount] = {"inner", "sphere", "cube", "leaf", "shade", "sky", "lambert", "metal", "glass", "start", "trav_round"};
@@ -405,6 +444,11 @@ int32_t collect_stats(rthip_ctx* c) {
 			for (int k = 0; k < kRegCount; k++)
 				std::fprintf(f, "%s lane_iters %llu wave_iters %llu util %.3f\n", names[k], s[5 + k], s[5 + kRegCount + k],
 				             s[5 + kRegCount + k] ? (double)s[5 + k] / (64.0 * (double)s[5 + kRegCount + k]) : 0.0);
+			// wave clock ticks (s_memtime) per phase of the main loop, summed over the waves, and their share of the waves' lifetime
+			static const char* phases[kPhCount] = {"shade", "regen", "fresh", "inner", "leaf", "total"};
+			for (int k = 0; k < kPhCount; k++)
+				std::fprintf(f, "phase %s ticks %llu share %.3f\n", phases[k], s[5 + 2 * kRegCount + k],
+				             s[5 + 2 * kRegCount + kPhTotal] ? (double)s[5 + 2 * kRegCount + k] / (double)s[5 + 2 * kRegCount + kPhTotal] : 0.0);
 			std::fclose(f);
 		}
 	}
@@ -545,6 +589,8 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		BuildOptions& b = c->build_opt;
 		if (k == "scene_lds") t.scene_lds = iv;
 		else if (k == "qnodes") t.qnodes = iv;
+		else if (k == "mats_lds") t.mats_lds = iv;
+		else if (k == "acc_lds") t.acc_lds = iv;
 		else if (k == "threads") t.threads = iv;
 		else if (k == "blocks_per_cu") t.blocks_per_cu = iv;
 		else if (k == "chunk") t.chunk = iv;

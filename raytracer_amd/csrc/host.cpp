@@ -908,6 +908,9 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 			auto up = [](size_t v) { return (v + 63) / 64 * 64; };
 			size_t scene = up(out->nodes32.size() * sizeof(Node<float>)) + up(out->prims32.size() * sizeof(Prim<float>)) + up(out->gates32.size() * sizeof(Gate<float>));
 			if (scene > 64 * 1024) return 0;
+			// (Launches may pick two workgroups of 768 threads with the materials in LDS as well when that keeps
+			// as many waves; the tree is sized for three of 512, which measured best: the room 768 threads
+			// free is worth more as material storage than as a finer tree.)
 			int best = 0;
 			for (int threads : {256, 512}) {
 				size_t per = (size_t)std::max(1, b.max_depth) * (size_t)threads * 4 + scene;
@@ -948,6 +951,19 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		}
 	}
 	lap("device tree");
+	// materials in primitive order: shading reads the record of the primitive that was hit without a
+	// trip through the primitive's object id, and small scenes keep the array in LDS beside the primitives
+	{
+		std::vector<Mat<float>> m32(out->prims32.size());
+		std::vector<Mat<double>> m64(out->prims64.size());
+		for (size_t i = 0; i < out->prims32.size(); i++) {
+			const size_t id = (size_t)(out->prims32[i].id & ((1 << kMatShift) - 1));
+			m32[i] = out->mats32[id];
+			m64[i] = out->mats64[id];
+		}
+		out->mats32.swap(m32);
+		out->mats64.swap(m64);
+	}
 	out->depth = std::max(1, b.max_depth);
 	if (use_sah && !big_ids_empty) { out->big_leaf = out->nodes32[0].child[0]; out->start = out->nodes32[0].child[1]; }
 	if (out->depth > kStackMax) { *err = "tree deeper than the traversal stack"; return false; }

@@ -52,7 +52,8 @@ template <typename Real>
 struct RenderArgs {
 	const char* scene;  // [nodes | prims | gates | mats] blob in HBM, each part 64-byte aligned
 	uint32_t prims_off, mats_off, gates_off, scene_bytes;
-	uint32_t lds_bytes;     // leading part of the blob that LDS-resident launches copy (all but the materials)
+	uint32_t acc_tile_off;  // kAccLds: byte offset in LDS of the waves' accumulation tiles (1536 bytes per wave)
+	uint32_t lds_bytes;     // leading part of the blob that LDS-resident launches copy: nodes, primitives, gates, and (kLds == 2) the materials
 	uint32_t qnodes_off;    // quantised nodes (f32 blobs of large scenes), 0 = none
 	QFrame qframe;          // their grid
 	int32_t big_leaf;       // leaf code of the oversized primitives every ray tests first, 0 = none
@@ -465,10 +466,28 @@ struct Tally { uint32_t box, sphere, cube; };
 // lanes) and the wave-iterations issued (counted by the first active lane), whose ratio / 64
 // is the SIMD lane utilisation of that region.
 enum : int { kRegInner = 0, kRegSphere, kRegCube, kRegLeaf, kRegShade, kRegSky, kRegLambert, kRegMetal, kRegGlass, kRegStart, kRegTravRound, kRegCount };
-struct Regions { uint32_t lane[kRegCount], wave[kRegCount]; };
+// Instrumented builds also clock the phases of the wave's main loop (s_memtime, wave-uniform).
+enum : int { kPhShade = 0, kPhRegen, kPhFresh, kPhInner, kPhLeaf, kPhTotal, kPhCount };
+struct Regions { uint32_t lane[kRegCount], wave[kRegCount]; unsigned long long clk[kPhCount]; };
+template <bool kCount>
+__device__ __forceinline__ unsigned long long phase_begin() {
+	if constexpr (kCount) return __builtin_amdgcn_s_memtime();
+	else return 0ull;
+}
+template <bool kCount>
+__device__ __forceinline__ void phase_end(Regions& rg, int phase, unsigned long long t0) {
+	if constexpr (kCount) rg.clk[phase] += __builtin_amdgcn_s_memtime() - t0;
+}
+// RT_CLOCK_ONLY (variant builds): instrumented launches keep the phase clocks but drop the per-iteration
+// tallies, which slow the kernel 2.5x and distort the shares.
+#ifdef RT_CLOCK_ONLY
+constexpr bool kTally = false;
+#else
+constexpr bool kTally = true;
+#endif
 template <bool kCount>
 __device__ __forceinline__ void region_tick(Regions& rg, int slot) {
-	if constexpr (kCount) {
+	if constexpr (kCount && kTally) {
 		rg.lane[slot]++;
 		unsigned long long m = __ballot(1);
 		if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) rg.wave[slot]++;
@@ -498,7 +517,7 @@ __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& 
 		bool hl = hit_box<Real>(n.box, r, tv.best_t, &el);
 		bool hr = hit_box<Real>(n.box + 6, r, tv.best_t, &er);
 		int32_t cl = n.child[0], cr = n.child[1];
-		if (kCount) tally.box += 2;
+		if (kCount && kTally) tally.box += 2;
 		if (hl && hr) {
 			bool right_first = er < el;  // nearer child first, the left one on equal entry
 			stack[tv.sp * kThreads] = right_first ? cl : cr;
@@ -535,7 +554,7 @@ __device__ __forceinline__ void trav_inner_q(Trav<float>& tv, const TravRay<floa
 		bool hl = hit_box_q(pl, r.qscale, r.qneg, r.noi, r.eps, tv.best_t, &el);
 		bool hr = hit_box_q(pl + 6, r.qscale, r.qneg, r.noi, r.eps, tv.best_t, &er);
 		int32_t cl = (int32_t)b.z, cr = (int32_t)b.w;
-		if (kCount) tally.box += 2;
+		if (kCount && kTally) tally.box += 2;
 		if (hl && hr) {
 			bool right_first = er < el;
 			stack[tv.sp * kThreads] = right_first ? cl : cr;
@@ -567,7 +586,7 @@ __device__ __forceinline__ void leaf_tests(Trav<Real>& tv, const TravRay<Real>& 
 		int32_t i = first + k;
 		Real t;
 		region_tick<kCount>(rg, kRegSphere);
-		if (kCount) tally.sphere++;
+		if (kCount && kTally) tally.sphere++;
 		if (hit_sphere<Real>(prims[i], r, &t) && better(t, i)) {
 			// a gated (inverted) sphere counts only if the reference would have reached it
 			const uint32_t n_gates = prim_gate_count(prims[i]), first_gate = prim_gate_first(prims[i]);
@@ -580,7 +599,7 @@ __device__ __forceinline__ void leaf_tests(Trav<Real>& tv, const TravRay<Real>& 
 		int32_t i = first + ns + k;
 		Real t;
 		region_tick<kCount>(rg, kRegCube);
-		if (kCount) tally.cube++;
+		if (kCount && kTally) tally.cube++;
 		if (hit_cube<Real>(prims[i], r, &t) && better(t, i)) { tv.best_t = t; tv.best_prim = i; }
 	}
 }
@@ -715,7 +734,7 @@ RT_FN bool shade_ray(const TravRay<Real>& ray, Real best_t, int32_t best_prim, c
 	}
 	const Prim<Real>& pr = prims[best_prim];
 	// the material record comes from global memory: ask for it before the hit record is worked out
-	const Mat<Real> mat = mats[pr.id & ((1 << kMatShift) - 1)];
+	const Mat<Real> mat = mats[best_prim];  // materials are stored in primitive order: no trip through the primitive's id
 	Hit<Real> h = make_hit<Real>(pr, ((pr.id >> kKindShift) & 1) == RTHIP_SPHERE, ray, best_t);
 	Scattered<Real> sc = scatter<Real>(h, mat, unit_dir, rng);
 	if (!sc.ok) return false;
@@ -771,9 +790,18 @@ enum : int { kIdle = 0, kTraverse = 1, kShade = 2, kFresh = 3 };
 // ---------------------------------------------------------------------------------------
 // The megakernel.
 // ---------------------------------------------------------------------------------------
-template <typename Real, int kThreads, bool kLds, bool kCount, bool kQ = false>
+// kLds: 0 = the scene is read from global memory; 1 = nodes, primitives and gates are copied to LDS;
+// 2 = the materials as well (they are read once per ray, and that one trip to L2 per bounce is worth
+// 6-7 % when LDS has the room).
+// kAccLds: finished paths add their sample to a 192-word tile that the wave keeps in LDS, and the
+// tile goes to the accumulation buffer once per work item (one atomic per word per item instead of
+// three per path).  A wave then finishes every path of an item before it takes the next one, so that
+// its tile belongs to one item at a time.  For scenes whose paths are a ray or two long, where the
+// accumulation atomics were what bounded the kernel (the three-object 4K scene ran at the same speed
+// with and without its camera's defocus arithmetic), and only where LDS has the room.
+template <typename Real, int kThreads, int kLds, bool kCount, bool kQ = false, bool kAccLds = false>
 __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? (kThreads == 1024 ? 8 : (kQ ? RT_QWAVES : RT_MINWAVES)) : 2)) void render_kernel(RenderArgs<Real> A) {
-	static_assert(!kQ || (!kLds && std::is_same<Real, float>::value), "quantised nodes: f32 trees in global memory only");
+	static_assert(!kQ || (kLds == 0 && std::is_same<Real, float>::value), "quantised nodes: f32 trees in global memory only");
 	extern __shared__ __align__(64) char smem[];
 	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kThreads]
 	const uint32_t stack_bytes = (uint32_t)A.stack_entries * kThreads * 4u;
@@ -788,7 +816,8 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 		__syncthreads();
 		nodes = reinterpret_cast<const Node<Real>*>(dst);
 		prims = reinterpret_cast<const Prim<Real>*>(dst + A.prims_off);
-		mats = reinterpret_cast<const Mat<Real>*>(A.scene + A.mats_off);  // read once per ray: left in HBM / L2
+		if constexpr (kLds == 2) mats = reinterpret_cast<const Mat<Real>*>(dst + A.mats_off);
+		else mats = reinterpret_cast<const Mat<Real>*>(A.scene + A.mats_off);  // read once per ray: from L2 when LDS has no room
 		gates = reinterpret_cast<const Gate<Real>*>(dst + A.gates_off);
 	} else {
 		nodes = reinterpret_cast<const Node<Real>*>(A.scene);
@@ -797,6 +826,21 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 		gates = reinterpret_cast<const Gate<Real>*>(A.scene + A.gates_off);
 	}
 	const uint32_t lane = threadIdx.x & 63u;
+	// the wave's accumulation tile (kAccLds): [channel][64 px] words behind the stacks and the scene copy
+	unsigned long long* acc_tile = nullptr;
+	unsigned long long* acc_dst = A.accum;  // where the tile belongs in the accumulation buffer
+	if constexpr (kAccLds) {
+		acc_tile = reinterpret_cast<unsigned long long*>(smem + A.acc_tile_off) + (threadIdx.x >> 6) * (kTilePixels * kAccumChannels);
+		for (int k = 0; k < kAccumChannels; k++) acc_tile[k * kTilePixels + lane] = 0ull;
+	}
+	auto flush_tile = [&]() {  // every lane of the wave: its pixel's three words
+		if constexpr (kAccLds) {
+			for (int k = 0; k < kAccumChannels; k++) {
+				const unsigned long long v = acc_tile[k * kTilePixels + lane];
+				if (v) { atomicAdd(acc_dst + k * kTilePixels + lane, v); acc_tile[k * kTilePixels + lane] = 0ull; }
+			}
+		}
+	};
 
 	// lane state
 	int state = kIdle;
@@ -819,13 +863,24 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	// counter.  Workgroups whose index agrees modulo 8 share an XCD and its L2, so they start on the
 	// same range and the rays an L2 serves stay in one part of the scene; a wave whose range is
 	// exhausted moves on to the next one (all ranges get finished whatever the placement).
+	const unsigned long long t_kernel = phase_begin<kCount>();
 	uint32_t item = 0, pool_pos = 0, pool_end = 0, queue_hop = 0;
 	const uint32_t home_queue = blockIdx.x % kQueues;
 	bool queue_dry = false;
 	const uint32_t pool_size = 64u * A.chunk;
+	// f32 kernels with registers to spare make their camera rays in batches (see the regeneration step)
+#ifdef RT_NO_BATCH_REGEN
+	constexpr bool kBatchRegen = false;
+#else
+	constexpr bool kBatchRegen = std::is_same<Real, float>::value && !kQ;
+#endif
+	V3<Real> sp_o = mk<Real>(0, 0, 0), sp_d = sp_o;
+	uint32_t sp_state = 0, sp_inc = 1, sp_accum = 0xFFFFFFFFu, sp_slot = 0;
+	uint32_t spare_pos = 0, spare_end = 0;
 
 	for (;;) {
 		// ---- shading ---------------------------------------------------------------------
+		unsigned long long t_ph = phase_begin<kCount>();
 		if (state == kShade) {
 			region_tick<kCount>(rg, kRegShade);
 			n_rays++;
@@ -838,18 +893,31 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 					Real* so = A.samples_out + (size_t)sample_slot * 3;
 					so[0] = L.x; so[1] = L.y; so[2] = L.z;
 				}
-				accumulate_sample<Real>(A.accum, accum_index, L);
+				if constexpr (kAccLds) {
+					unsigned long long* acc = acc_tile + (accum_index & 63u);
+					atomicAdd(acc, to_fixed<Real>(Fp<Real>::sqrt(L.x)));
+					atomicAdd(acc + kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L.y)));
+					atomicAdd(acc + 2 * kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L.z)));
+				} else {
+					accumulate_sample<Real>(A.accum, accum_index, L);
+				}
 				state = kIdle;
 			}
 		}
 
+		phase_end<kCount>(rg, kPhShade, t_ph);
+		t_ph = phase_begin<kCount>();
 		// ---- regeneration: hand idle lanes the next paths of the wave's pool -------------
 		for (;;) {
 			unsigned long long need = __ballot(state == kIdle);
 			if (need == 0ull) break;
 			if ((int32_t)__popcll(need) < A.regen_min && need != ~0ull) break;  // wait for more idle lanes: camera rays for few lanes waste the wave
-			if (pool_pos == pool_end) {
+			if (pool_pos == pool_end && (!kBatchRegen || spare_pos == spare_end)) {
 				if (queue_dry) break;
+				if constexpr (kAccLds) {
+					if (need != ~0ull) break;  // paths of the current item are still in flight: the tile is theirs
+					flush_tile();
+				}
 				bool got = false;
 				while (queue_hop < kQueues) {
 					const uint32_t q = (home_queue + queue_hop) % kQueues;
@@ -863,7 +931,60 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				}
 				if (!got) { queue_dry = true; break; }
 				pool_pos = 0; pool_end = pool_size;
+				if constexpr (kAccLds) {  // the item's tile (work items of LDS-resident scenes run in plain tile order)
+					const uint32_t tile = (uint32_t)A.part_index + (item / A.n_chunks) * (uint32_t)A.part_count;
+					acc_dst = A.accum + (size_t)tile * (kTilePixels * kAccumChannels);
+				}
 			}
+			if constexpr (kBatchRegen) {
+				// Camera rays are made 64 at a time, by all lanes together, and parked one per lane (the
+				// "spares"); idle lanes then pick theirs up from whichever lane holds it (ds_bpermute).
+				// Making them on demand ran ray generation, a sixth of the kernel's arithmetic, on the
+				// 16-30 lanes that happened to be idle.
+				if (spare_pos == spare_end) {
+					const uint32_t n = min(64u, pool_end - pool_pos);
+					sp_accum = 0xFFFFFFFFu;  // no path: outside the image, or a sample beyond spp_count
+					PathId id;
+					if (lane < n && decode_path(item, pool_pos + lane, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order)) {
+						Rng g;
+						g.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
+						const RayT<Real> r = camera_ray<Real>(A.cam, (Real)id.px, (Real)id.py, g, true);
+						sp_o = r.o; sp_d = r.d;
+						sp_state = g.state; sp_inc = g.inc;
+						sp_accum = id.accum_index;
+						sp_slot = (id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px;
+						region_tick<kCount>(rg, kRegStart);
+					}
+					pool_pos += n;
+					spare_pos = 0; spare_end = n;
+				}
+				const uint32_t want = (uint32_t)__popcll(need), avail = spare_end - spare_pos;
+				const uint32_t take = want < avail ? want : avail;
+				const uint32_t rk = lane_rank(need);
+				const bool mine = state == kIdle && rk < take;
+				const int src = mine ? (int)(spare_pos + rk) : (int)lane;  // every lane takes part in the exchange
+				const Real ox = __shfl(sp_o.x, src, 64), oy = __shfl(sp_o.y, src, 64), oz = __shfl(sp_o.z, src, 64);
+				const Real dx = __shfl(sp_d.x, src, 64), dy = __shfl(sp_d.y, src, 64), dz = __shfl(sp_d.z, src, 64);
+				const uint32_t g_state = (uint32_t)__shfl((int)sp_state, src, 64), g_inc = (uint32_t)__shfl((int)sp_inc, src, 64);
+				const uint32_t g_accum = (uint32_t)__shfl((int)sp_accum, src, 64), g_slot = (uint32_t)__shfl((int)sp_slot, src, 64);
+				if (mine && g_accum != 0xFFFFFFFFu) {
+					rng.state = g_state; rng.inc = g_inc;
+					accum_index = g_accum;
+					sample_slot = g_slot;
+					T = mk<Real>(1, 1, 1);
+					L = mk<Real>(0, 0, 0);
+					depth = A.max_depth;
+					n_paths++;
+					if (depth > 0) {
+						ray.o = mk<Real>(ox, oy, oz); ray.d = mk<Real>(dx, dy, dz);
+						state = kFresh;
+					} else if (A.samples_out) {  // renderer.rs:10-12: depth <= 0 -> black
+						Real* so = A.samples_out + (size_t)sample_slot * 3;
+						so[0] = so[1] = so[2] = Real(0);
+					}
+				}
+				spare_pos += take;
+			} else {
 			uint32_t want = (uint32_t)__popcll(need);
 			uint32_t avail = pool_end - pool_pos;
 			uint32_t take = want < avail ? want : avail;
@@ -871,7 +992,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				uint32_t rk = lane_rank(need);
 				if (rk < take) {
 					PathId id;
-					if (decode_path(item, pool_pos + rk, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds ? 0u : A.block_order)) {
+					if (decode_path(item, pool_pos + rk, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order)) {
 						rng.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
 						RayT<Real> r = camera_ray<Real>(A.cam, (Real)id.px, (Real)id.py, rng, true);
 						accum_index = id.accum_index;
@@ -892,8 +1013,11 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				}
 			}
 			pool_pos += take;
+			}
 		}
+		phase_end<kCount>(rg, kPhRegen, t_ph);
 		if (__ballot(state != kIdle) == 0ull) break;
+		t_ph = phase_begin<kCount>();
 		// rays made above by shading (next bounce) and by regeneration (camera rays) are set up together
 		if (state == kFresh) {
 			trav_begin<Real>(tv);
@@ -908,6 +1032,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			}
 			state = kTraverse;
 		}
+		phase_end<kCount>(rg, kPhFresh, t_ph);
 
 		// ---- traversal: until few lanes are left traversing while others wait -------------
 		for (;;) {
@@ -917,26 +1042,35 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			if ((int32_t)n_trav <= A.trav_threshold) {
 				// lanes that shading or regeneration would serve right now (idle lanes only count once
 				// there are enough of them for regeneration to accept, so leaving here always makes progress)
-				const bool refill = !queue_dry && (int32_t)__popcll(__ballot(state == kIdle)) >= A.regen_min;
+				// (with the LDS tile, an exhausted item is refilled only once all its paths are done: nothing to serve before)
+				const bool paths_at_hand = !kAccLds || pool_pos != pool_end || (kBatchRegen && spare_pos != spare_end);
+				const bool refill = !queue_dry && paths_at_hand && (int32_t)__popcll(__ballot(state == kIdle)) >= A.regen_min;
 				if (refill || __ballot(state == kShade) != 0ull) break;
 			}
 			if (state == kTraverse) {
 				region_tick<kCount>(rg, kRegTravRound);
+				t_ph = phase_begin<kCount>();
 				if constexpr (kQ) trav_inner_q<kThreads, kCount>(tv, ray, reinterpret_cast<const QNode*>(A.scene + A.qnodes_off), stack, tally, rg, A.inner_exit);
 				else trav_inner<Real, kThreads, kCount>(tv, ray, nodes, stack, tally, rg, A.inner_exit);
+				phase_end<kCount>(rg, kPhInner, t_ph);
+				t_ph = phase_begin<kCount>();
 				if (tv.cur < 0 && tv.cur != kDone) trav_leaf<Real, kThreads, kCount>(tv, ray, prims, gates, stack, tally, rg);
+				phase_end<kCount>(rg, kPhLeaf, t_ph);
 				if (tv.cur == kDone) state = kShade;
 			}
 		}
 
 	}
 
+	flush_tile();
 	// ---- statistics: one atomic per wave ------------------------------------------------
-	unsigned long long v[5 + 2 * kRegCount] = {n_paths, n_rays, tally.box, tally.sphere, tally.cube};
+	unsigned long long v[5 + 2 * kRegCount + kPhCount] = {n_paths, n_rays, tally.box, tally.sphere, tally.cube};
 	if constexpr (kCount) {
+		rg.clk[kPhTotal] = __builtin_amdgcn_s_memtime() - t_kernel;
 		for (int k = 0; k < kRegCount; k++) { v[5 + k] = rg.lane[k]; v[5 + kRegCount + k] = rg.wave[k]; }
+		for (int k = 0; k < kPhCount; k++) v[5 + 2 * kRegCount + k] = lane == 0 ? rg.clk[k] : 0ull;  // wave-uniform: counted once
 	}
-	const int nstat = kCount ? 5 + 2 * kRegCount : 2;
+	const int nstat = kCount ? 5 + 2 * kRegCount + kPhCount : 2;
 	for (int k = 0; k < nstat; k++) {
 		unsigned long long s = v[k];
 		for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

@@ -9,12 +9,16 @@
 namespace rthip {
 
 struct LaunchCfg {
+	int device;          // HIP device the launch goes to
 	int grid;            // workgroups
-	int threads;         // threads per workgroup: 256 or 512
+	int threads;         // threads per workgroup: 256, 512, 768 or 1024
 	size_t dyn_lds;      // bytes of dynamic LDS
 	bool scene_in_lds;
+	int lds_mode;        // render kernel: 0 = scene in global memory, 1 = nodes / primitives / gates in LDS, 2 = materials too
 	bool count;          // instrumented (box / sphere / cube test counters)
 	bool quantised;      // f32, scene in global memory: traverse the 32-byte quantised nodes
+	uint32_t acc_tile_off;  // acc_lds: where the tiles start in the workgroup's dynamic LDS
+	bool acc_lds;        // f32, lds_mode 2: samples go to a per-wave tile in LDS, flushed once per work item
 };
 
 hipError_t launch_render(const RenderArgs<float>& a, const LaunchCfg& cfg, hipStream_t s);
@@ -22,8 +26,8 @@ hipError_t launch_render(const RenderArgs<double>& a, const LaunchCfg& cfg, hipS
 hipError_t launch_probe(const ProbeArgs<float>& a, size_t dyn_lds, hipStream_t s);
 hipError_t launch_probe(const ProbeArgs<double>& a, size_t dyn_lds, hipStream_t s);
 // Resident workgroups per CU for the render kernel at this much dynamic LDS.
-hipError_t render_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks, bool quantised = false);
-hipError_t render_blocks_per_cu_f64(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks);
+hipError_t render_blocks_per_cu_f32(int threads, int lds_mode, size_t dyn_lds, int* blocks, bool quantised = false, bool acc_lds = false);
+hipError_t render_blocks_per_cu_f64(int threads, int lds_mode, size_t dyn_lds, int* blocks);
 // Accumulation buffer (tile-major fixed point) -> row-major [H][W][3] doubles (sums).
 hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x, hipStream_t s);
 // raytracer_headless/src/main.rs:6-12,55: (accum / spp * 255.0) as u8.  xrgb = 0: RGB8 bytes

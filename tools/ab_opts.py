@@ -1,0 +1,18 @@
+"""A/B of option sets (rthip_set_option names) on the two bench workloads, one process:
+python tools/ab_opts.py "sah_cprim=0.4,mats_lds=0" "sah_cprim=0.4,threads=768" ...   ('-' = defaults)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as rt
+CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
+sets = sys.argv[1:] or ["-"]
+for which, scene, depth in (("cfg2", "default", 10), ("cfg3", "sample", 50)):
+    sc = rt.Scene.generate(scene)
+    for spec in sets:
+        opts = {} if spec == "-" else {k: float(v) for k, v in (kv.split("=") for kv in spec.split(","))}
+        r = rt.Renderer(sc, rt.Camera(*CAM, 1920, 1080), max_depth=depth, seed=1, options=opts)
+        best = 0
+        for _ in range(4):
+            r.reset_accumulation(); r.accumulate(32, spp_begin=0)
+            s = r.stats(); best = max(best, s["paths"] / s["kernel_ms"] / 1e3)
+        print(f"{which} {spec:40s} {best:8.0f} Mpaths/s  nodes {s['n_nodes']} prims {s['n_prims']} depth {s['tree_depth']} lds {s['scene_in_lds']}", flush=True)
+        r.close()

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
-os.environ["RTHIP_COUNT"] = "1"
+os.environ["RTHIP_COUNT"] = "1"   # read when the context is created
 for which, scene, depth in (("cfg2", "default", 10), ("cfg3", "sample", 50)):
     path = f"gpurun_out/regions_{which}.txt"
     if os.path.exists(path): os.remove(path)
