@@ -50,8 +50,8 @@ struct Tuning {
 	int blocks_per_cu = 0;    // RTHIP_BLOCKS_PER_CU: cap on resident workgroups per CU, 0 = none
 	int chunk = 0;            // RTHIP_CHUNK: samples of a tile per work item, 0 = by launch size
 	int trav_threshold = -1;  // RTHIP_TRAV_THRESHOLD: -1 = 14 (scene in LDS) / 36 (global memory)
-	int inner_exit = -1;      // RTHIP_INNER_EXIT: sixteenths, -1 = 5 (LDS) / 8 (global memory)
-	int regen_min = 16;       // RTHIP_REGEN_MIN
+	int inner_exit = -1;      // RTHIP_INNER_EXIT: sixteenths, -1 = 4 (LDS) / 8 (global memory)
+	int regen_min = 12;       // RTHIP_REGEN_MIN (12 since camera rays are made in batches: handing them out is cheap)
 	int block_order = 32;     // RTHIP_BLOCK_ORDER
 	int wf_batch = 64 << 20;  // RTHIP_WF_BATCH: paths per batch of the wavefront variant
 	int count = 0;            // RTHIP_COUNT: instrumented launches (test tallies, region counters)
@@ -341,7 +341,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.sky_mode = p->sky_mode; a.part_index = p->part_index; a.part_count = p->part_count;
 	a.n_items = plan.n_items; a.chunk = plan.chunk; a.n_chunks = plan.n_chunks; a.trav_threshold = plan.threshold;
 	// sixteenths of the lanes that entered a round; beyond 16 no lane would ever take a step
-	a.inner_exit = std::max(0, std::min(16, c->tune.inner_exit >= 0 ? c->tune.inner_exit : (plan.cfg.scene_in_lds ? 5 : 8)));
+	a.inner_exit = std::max(0, std::min(16, c->tune.inner_exit >= 0 ? c->tune.inner_exit : (plan.cfg.scene_in_lds ? 4 : 8)));
 	a.regen_min = std::max(1, std::min(64, c->tune.regen_min));
 	a.block_order = (uint32_t)std::max(0, std::min(1024, c->tune.block_order));
 	a.accum = accum; a.samples_out = samples_out;

@@ -1,18 +1,26 @@
-"""A/B of option sets (rthip_set_option names) on the two bench workloads, one process:
-python tools/ab_opts.py "sah_cprim=0.4,mats_lds=0" "sah_cprim=0.4,threads=768" ...   ('-' = defaults)"""
+"""A/B of option sets (rthip_set_option names; the old per-variable sweeps in one tool) on bench
+workloads, one process:
+  python tools/ab_opts.py [--wl cfg2,cfg3,cfg5] "sah_cprim=0.4,mats_lds=0" "threads=768" ...   ('-' = defaults)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
-sets = sys.argv[1:] or ["-"]
-for which, scene, depth in (("cfg2", "default", 10), ("cfg3", "sample", 50)):
+CAM5 = ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0)
+WL = {"cfg2": ("default", 10, CAM, 32), "cfg3": ("sample", 50, CAM, 32), "cfg5": ("synthetic:1000000", 50, CAM5, 8)}
+args = sys.argv[1:]
+which = ["cfg2", "cfg3"]
+if args and args[0] == "--wl":
+    which, args = args[1].split(","), args[2:]
+sets = args or ["-"]
+for name in which:
+    scene, depth, cam, spp = WL[name]
     sc = rt.Scene.generate(scene)
     for spec in sets:
         opts = {} if spec == "-" else {k: float(v) for k, v in (kv.split("=") for kv in spec.split(","))}
-        r = rt.Renderer(sc, rt.Camera(*CAM, 1920, 1080), max_depth=depth, seed=1, options=opts)
+        r = rt.Renderer(sc, rt.Camera(*cam, 1920, 1080), max_depth=depth, seed=1, options=opts)
         best = 0
         for _ in range(4):
-            r.reset_accumulation(); r.accumulate(32, spp_begin=0)
+            r.reset_accumulation(); r.accumulate(spp, spp_begin=0)
             s = r.stats(); best = max(best, s["paths"] / s["kernel_ms"] / 1e3)
-        print(f"{which} {spec:40s} {best:8.0f} Mpaths/s  nodes {s['n_nodes']} prims {s['n_prims']} depth {s['tree_depth']} lds {s['scene_in_lds']}", flush=True)
+        print(f"{name} {spec:40s} {best:8.0f} Mpaths/s  nodes {s['n_nodes']} prims {s['n_prims']} depth {s['tree_depth']} lds {s['scene_in_lds']}", flush=True)
         r.close()

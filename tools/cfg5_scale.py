@@ -4,13 +4,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 cam = rt.Camera((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0, 1920, 1080)
-os.environ["RTHIP_SCENE_LDS"] = "0"
 for n in (3000, 30000, 100000, 300000, 1000000, 3000000):
     sc = rt.create_synthetic_scene(n, seed=0x5EED0001)
-    r = rt.Renderer(sc, cam, max_depth=50, seed=1)
-    os.environ["RTHIP_COUNT"] = "1"
+    r = rt.Renderer(sc, cam, max_depth=50, seed=1, options={"scene_lds": 0})
+    r.set_option("count", 1)
     r.accumulate(4, spp_begin=0); c = r.stats()
-    os.environ["RTHIP_COUNT"] = "0"
+    r.set_option("count", 0)
     best = None
     for _ in range(2):
         r.reset_accumulation(); r.accumulate(8, spp_begin=0); s = r.stats()

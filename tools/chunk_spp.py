@@ -10,7 +10,7 @@ for which, scene, depth, cam, size, sky in (("cfg2", "default", 10, CAM, (1920, 
     for spp in (4, 16, 32, 100, 256, 500):
         row = []
         for chunk in (2, 4, 8, 16, 32):
-            os.environ["RTHIP_CHUNK"] = str(chunk)
+            r.set_option("chunk", chunk)
             best = 0.0
             for _ in range(2 if spp > 100 else 3):
                 r.reset_accumulation(); r.accumulate(spp, spp_begin=0); s = r.stats()

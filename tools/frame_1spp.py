@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 r = rt.Renderer(rt.Scene.generate("default"), rt.Camera(*CAM, 1920, 1080), max_depth=10, seed=1)
-for env in ({}, {"RTHIP_THREADS": "256"}, {"RTHIP_BLOCKS_PER_CU": "2"}, {"RTHIP_BLOCKS_PER_CU": "1"}, {"RTHIP_REGEN_MIN": "1"}, {"RTHIP_TRAV_THRESHOLD": "24"}):
-    for k in ("RTHIP_THREADS", "RTHIP_BLOCKS_PER_CU", "RTHIP_REGEN_MIN", "RTHIP_TRAV_THRESHOLD"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+DEFAULTS = {"threads": 0, "blocks_per_cu": 0, "regen_min": 12, "trav_threshold": -1}
+for env in ({}, {"threads": 256}, {"blocks_per_cu": 2}, {"blocks_per_cu": 1}, {"regen_min": 1}, {"trav_threshold": 24}):
+    for k, v in {**DEFAULTS, **env}.items():
+        r.set_option(k, v)
     for spp in (1, 2, 4):
         r.reset_accumulation()
         for _ in range(3):
