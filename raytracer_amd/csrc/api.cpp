@@ -241,12 +241,19 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// waves resident.  Every workgroup holds its own LDS copy of the scene, so larger workgroups
 	// amortise it; among equals, the one that has room for the materials too wins (tried first).
 	const int forced = tune.threads;
+	uint64_t n_tiles = (uint64_t)c->tiles_x * c->tiles_y;
+	uint64_t my_tiles = n_tiles > (uint64_t)p->part_index ? (n_tiles - p->part_index + p->part_count - 1) / p->part_count : 0;
+	// Short launches (a viewer's 1-spp frame at 1080p: ~340 paths per resident wave) are all start-up
+	// and tail: small workgroups start sooner and finish closer together, which is worth more there than
+	// resident waves (0.38 ms against 0.46 ms for that frame).
+	const bool short_launch = in_lds && !wavefront && my_tiles * kTilePixels * (uint64_t)p->spp_count < 512ull * 24 * (uint64_t)c->num_cu;
 	int best_waves = -1, bpc = 0;
 	for (int lds_mode : {2, 1, 0}) {
 		if ((lds_mode != 0) != in_lds) continue;
 		if (lds_mode == 2 && (wavefront || tune.mats_lds == 0 || blob.lds_bytes_mats > kLdsSceneLimit)) continue;
 		for (int threads : {256, 512, 768, 1024}) {
 			if (forced && threads != forced) continue;
+			if (short_launch && !forced && threads != 256) continue;
 			if (threads == 1024 && (wavefront || forced != 1024 || lds_mode == 2)) continue;  // 32 waves per CU at 64 VGPRs measured no faster than 24 at 80: on request only
 			if (threads == 768 && lds_mode != 2) continue;  // two workgroups of twelve waves: only built for the variant that needs the room
 			size_t lds = (size_t)c->tree_depth * threads * 4 + (lds_mode == 2 ? blob.lds_bytes_mats : lds_mode == 1 ? blob.lds_bytes : 0);
@@ -285,8 +292,6 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	}
 	const int cap = tune.blocks_per_cu;
 	if (cap > 0) bpc = std::min(bpc, cap);
-	uint64_t n_tiles = (uint64_t)c->tiles_x * c->tiles_y;
-	uint64_t my_tiles = n_tiles > (uint64_t)p->part_index ? (n_tiles - p->part_index + p->part_count - 1) / p->part_count : 0;
 	// Samples of a tile per work item.  Small items balance short launches (the tail is one item per
 	// wave); long launches want fewer, larger items (millions of items contend on the queue counters
 	// and scatter a tile's accumulation lines).  Measured optimum: 4 up to ~128 spp, 8-16 beyond.

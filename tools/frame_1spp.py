@@ -1,14 +1,15 @@
 """The progressive viewer's case: one sample per pixel per launch at 1080p (cfg2 scene).
-Kernel time (HIP events) and wall time per frame, for a few launch shapes."""
+Kernel time (HIP events) and wall time per frame, for a few launch shapes (option sets)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 r = rt.Renderer(rt.Scene.generate("default"), rt.Camera(*CAM, 1920, 1080), max_depth=10, seed=1)
-DEFAULTS = {"threads": 0, "blocks_per_cu": 0, "regen_min": 12, "trav_threshold": -1}
-for env in ({}, {"threads": 256}, {"blocks_per_cu": 2}, {"blocks_per_cu": 1}, {"regen_min": 1}, {"trav_threshold": 24}):
+DEFAULTS = {"threads": 0, "blocks_per_cu": 0, "regen_min": 12, "trav_threshold": -1, "mats_lds": 1, "chunk": 0}
+sets = [{}] + [dict(kv.split("=") for kv in a.split(",")) for a in sys.argv[1:]]
+for env in sets:
     for k, v in {**DEFAULTS, **env}.items():
-        r.set_option(k, v)
+        r.set_option(k, float(v))
     for spp in (1, 2, 4):
         r.reset_accumulation()
         for _ in range(3):

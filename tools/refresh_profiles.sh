@@ -1,22 +1,22 @@
 #!/bin/bash
 # Regenerates, on the GPU box, everything kept under profiles/<tag>/: the bench lines of the four
-# workloads, the kernel trace of the default bench, and per-workload traces and counter passes.
+# workloads (one bench run carries cfg2-cfg5), the kernel trace of the default bench, per-workload
+# traces and counter passes, and the HBM bytes per path derived from them.
 # Results land in gpurun_out/refresh_<tag>/ ; copy what is to be kept into profiles/<tag>/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/refresh_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 step() { echo "[refresh] $*"; }
-step "bench cfg2 (default)"; timeout -k 10 400 python3 -u bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { tail -5 $OUT/bench_n1.err; exit 1; }
+step "bench cfg2 (default)"; timeout -k 10 500 python3 -u bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { tail -5 $OUT/bench_n1.err; exit 1; }
 step "bench cfg2 under rocprofv3 --kernel-trace --stats"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 bench.py --no-cpu --no-extra > $OUT/bench_n1_under_rocprof.json 2> $OUT/bench_trace.err || { tail -5 $OUT/bench_trace.err; exit 1; }
-step "bench cfg4"; timeout -k 10 300 python3 -u bench.py --workload cfg4 --steps 3 --warmup 1 --no-extra > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err || { tail -5 $OUT/bench_cfg4.err; exit 1; }
-step "bench cfg5"; timeout -k 10 600 python3 -u bench.py --workload cfg5 --steps 2 --warmup 1 --no-extra > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err || { tail -5 $OUT/bench_cfg5.err; exit 1; }
-for wl in cfg2 cfg3 cfg5; do
+for wl in cfg2 cfg3 cfg4 cfg5; do
 	step "profile $wl"; bash tools/profile.sh ${TAG}x $wl > $OUT/profile_$wl.log 2>&1 || { tail -5 $OUT/profile_$wl.log; exit 1; }
 	python3 tools/pmc_summary.py gpurun_out/prof_${TAG}x_$wl > $OUT/${wl}_pmc_summary.json 2>> $OUT/profile_$wl.log
 	cp $(find gpurun_out/prof_${TAG}x_$wl/trace -name "*kernel_stats.csv" | head -1) $OUT/${wl}_kernel_stats.csv
 done
 cp $(find $OUT/bench_trace -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+python3 tools/traffic_from_pmc.py $OUT $OUT/traffic.json > /dev/null
 step done; ls $OUT
