@@ -12,11 +12,13 @@
 #include <string>
 #include <vector>
 
+#include <zlib.h>
+
 #include "../../include/rthip.h"
 
 namespace {
 
-// ---- minimal PNG writer (RGB8, stored deflate blocks) ------------------------------------
+// ---- minimal PNG writer (RGB8, filter none, zlib deflate) ---------------------------------
 uint32_t crc_table[256];
 void crc_init() {
 	for (uint32_t n = 0; n < 256; n++) {
@@ -47,18 +49,11 @@ bool write_png(const std::string& path, const uint8_t* rgb, int w, int h) {
 		raw.push_back(0);  // filter: none
 		raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3);
 	}
-	std::vector<uint8_t> z = {0x78, 0x01};
-	uint32_t a = 1, b = 0;
-	for (uint8_t v : raw) { a = (a + v) % 65521u; b = (b + a) % 65521u; }
-	for (size_t pos = 0; pos < raw.size();) {
-		size_t n = std::min<size_t>(65535, raw.size() - pos);
-		z.push_back(pos + n == raw.size() ? 1 : 0);
-		z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
-		z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
-		z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
-		pos += n;
-	}
-	put32(z, (b << 16) | a);
+	// deflate through zlib, as the image crate does for RgbImage::save (raytracer_headless/src/main.rs:70-72)
+	uLongf zlen = compressBound((uLong)raw.size());
+	std::vector<uint8_t> z(zlen);
+	if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+	z.resize(zlen);
 	std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
 	std::vector<uint8_t> ihdr;
 	put32(ihdr, (uint32_t)w); put32(ihdr, (uint32_t)h);

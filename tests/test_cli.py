@@ -67,3 +67,42 @@ def test_cli_png_equals_library_readback(rt, tmp_path, scene, sky):
     r.accumulate(spp)
     assert np.array_equal(img, r.read_rgb8())
     r.close()
+
+
+@pytest.mark.gpu
+def test_cfg1_headless_default_render(rt, oracle, tmp_path):
+    """BASELINE configs[0]: raytracer_headless's own run (raytracer_headless/src/main.rs:15-28: default
+    scene, 2560x1440, depth 10, 800 spp) through the CLI with no size arguments.  The PNG equals the
+    library's read-back of the same 800 samples; the first two samples of that frame, at the full
+    2560x1440, are checked against the reference algorithm on the CPU (same stream: RMSE <= 2e-3);
+    and the 800-sample image agrees with that 2-sample CPU image within Monte-Carlo noise."""
+    seed = 0x5EED0001
+    png = str(tmp_path / "output.png")
+    out = subprocess.run([EXE, "--backend", "hip", "--out", png], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Rendering took" in out.stdout
+    img = read_png_rgb8(png)
+    assert img.shape == (1440, 2560, 3)
+    assert os.path.getsize(png) < 2560 * 1440 * 3           # deflated, as the image crate writes it
+    n = (13.0 * 13.0 + 1.5 * 1.5 + 3.0 * 3.0) ** 0.5
+    cam = ((13.0, 1.5, 3.0), (-(13.0 / n), -(1.5 / n), -(3.0 / n)), 20.0, 10.0, 0.6, 2560, 1440)
+    sc = rt.Scene.generate("default")
+    r = rt.Renderer(sc, rt.Camera(*cam), seed=seed, max_depth=10)
+    r.accumulate(2)
+    first2 = r.read_accum() / 2
+    for _ in range(798 // 100 + 1):
+        r.accumulate(min(100, 800 - r.spp_done))
+    assert r.spp_done == 800 and np.array_equal(img, r.read_rgb8())
+    full = r.read_accum() / 800
+    r.close()
+    osc = oracle.OracleScene(sc.objects)
+    ref2, _, cnt, _ = osc.render(oracle.camera_desc(*cam), 2, 10, seed, oracle.FAITHFUL)
+    ref2 = ref2 / 2
+    rmse = float(np.sqrt(((np.clip(first2, 0, 1) - np.clip(ref2, 0, 1)) ** 2).mean()))
+    assert rmse <= 2e-3, rmse
+    # converged GPU image against the noisy CPU one: no bias (3.7 M pixels: the frame means agree to 0.5 %;
+    # unclipped, since clipping a 2-sample mean and an 800-sample mean are different estimators)
+    a, b = full, ref2
+    assert abs(a.mean() - b.mean()) <= 5e-3 * b.mean(), (a.mean(), b.mean())
+    print(f"[cfg1] 2560x1440: first two samples RMSE {rmse:.2e} against the CPU reference algorithm ({cnt['rays']} rays); "
+          f"800-spp image mean {a.mean():.4f} against {b.mean():.4f}")
