@@ -1,6 +1,6 @@
 """A/B of option sets (rthip_set_option names; the old per-variable sweeps in one tool) on bench
 workloads, one process:
-  python tools/ab_opts.py [--wl cfg2,cfg3,cfg5] "sah_cprim=0.4,mats_lds=0" "threads=768" ...   ('-' = defaults)"""
+  python tools/ab_opts.py [--wl cfg2,cfg3,cfg5] [--spp N] "sah_cprim=0.4,mats_lds=0" "threads=768" ...   ('-' = defaults)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
@@ -11,9 +11,13 @@ args = sys.argv[1:]
 which = ["cfg2", "cfg3"]
 if args and args[0] == "--wl":
     which, args = args[1].split(","), args[2:]
+spp_override = None
+if args and args[0] == "--spp":
+    spp_override, args = int(args[1]), args[2:]
 sets = args or ["-"]
 for name in which:
     scene, depth, cam, spp = WL[name]
+    spp = spp_override or spp
     sc = rt.Scene.generate(scene)
     for spec in sets:
         opts = {} if spec == "-" else {k: float(v) for k, v in (kv.split("=") for kv in spec.split(","))}
@@ -22,5 +26,5 @@ for name in which:
         for _ in range(4):
             r.reset_accumulation(); r.accumulate(spp, spp_begin=0)
             s = r.stats(); best = max(best, s["paths"] / s["kernel_ms"] / 1e3)
-        print(f"{name} {spec:40s} {best:8.0f} Mpaths/s  nodes {s['n_nodes']} prims {s['n_prims']} depth {s['tree_depth']} lds {s['scene_in_lds']}", flush=True)
+        print(f"{name} spp {spp} {spec:40s} {best:8.0f} Mpaths/s  threads {s.get('threads', '?')} grid {s.get('grid', '?')} nodes {s['n_nodes']} prims {s['n_prims']} depth {s['tree_depth']} lds {s['scene_in_lds']}", flush=True)
         r.close()
