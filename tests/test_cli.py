@@ -81,6 +81,7 @@ def test_cfg1_headless_default_render(rt, oracle, tmp_path):
     out = subprocess.run([EXE, "--backend", "hip", "--out", png], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Rendering took" in out.stdout
+    print("[cfg1]", [l for l in out.stdout.splitlines() if "took" in l or "paths/s" in l])
     img = read_png_rgb8(png)
     assert img.shape == (1440, 2560, 3)
     assert os.path.getsize(png) < 2560 * 1440 * 3           # deflated, as the image crate writes it
