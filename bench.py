@@ -178,6 +178,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # Everything of this process (buffer zero-fills, renders, timing events) goes onto one stream of its
+    # own: torch's default stream has the handle 0, which the C ABI reads as "the context's own stream",
+    # and that one is not ordered against torch's operations.
+    torch.cuda.set_stream(torch.cuda.Stream(device))
     multi = world > 1 or args.rehearse_dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -215,8 +219,7 @@ def main():
         scene = rt.Scene.generate(wl["scene"], SCENE_SEED)
         cam = rt.Camera(*wl["camera"](), wl["width"], wl["height"])
         r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"], precision=precision)
-        stream = torch.cuda.current_stream(device)
-        r.set_stream(stream.cuda_stream)
+        r.set_torch_stream()
         pipe = make_pipeline(r, wl["width"], wl["height"])
         begin, count, part = share(wl["spp"])
 
@@ -294,7 +297,7 @@ def main():
         scene = rt.Scene.generate(wl["scene"] if len(wl["scene"]) < 12 else "default", SCENE_SEED)
         cam = rt.Camera(*wl["camera"](), w, h)
         r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"])
-        r.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        r.set_torch_stream()
         pipe = make_pipeline(r, w, h)
         begin, count, part = (rank * spp, spp, (0, 1)) if weak else share(spp)
         buf = pipe.acquire()

@@ -105,7 +105,7 @@ int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
 /* Tuning and build knobs (no counterpart in the reference, which has no configuration at all).
  * A context reads the RTHIP_* environment variables ONCE, in rthip_create; this call changes a
  * knob afterwards.  Names are the variable names in lower case without the prefix: launch knobs
- * "scene_lds", "qnodes", "threads", "blocks_per_cu", "chunk", "trav_threshold", "inner_exit",
+ * "scene_lds", "qnodes", "threads", "blocks_per_cu", "grid_reserve", "chunk", "trav_threshold", "inner_exit",
  * "regen_min", "block_order", "wf_batch", "count" take effect with the next render call; build
  * knobs "tree_ref" (1 = device tree in the reference's shape), "sah_leaf", "sah_cprim",
  * "sah_sweep", "big_leaf_min", "no_big_leaf", "no_qnodes", "build_threads", "tie_reverse"

@@ -177,6 +177,7 @@ class Renderer:
                  variant=N.MEGAKERNEL, options=None):
         self._lib = N.lib()
         self._ctx = C.c_void_p()
+        self.device = int(device)
         N.check(self._lib.rthip_create(int(device), C.byref(self._ctx)))
         for name, value in (options or {}).items():   # build knobs must be set before the scene is uploaded
             self.set_option(name, value)
@@ -214,7 +215,19 @@ class Renderer:
         self._check(self._lib.rthip_set_option(self._ctx, name.encode(), float(value)))
 
     def set_stream(self, stream_handle):
+        """Launch on a caller-owned hipStream_t; 0 = the context's own stream (which is NOT ordered
+        against the default stream: see set_torch_stream)."""
         self._check(self._lib.rthip_set_stream(self._ctx, C.c_void_p(stream_handle)))
+
+    def set_torch_stream(self, stream=None):
+        """Launch on a torch stream (default: the current one), so that torch operations on that
+        stream (zero_() of a caller-owned accumulation buffer, reads of it) and renders are ordered.
+        torch's default stream has the handle 0, which rthip_set_stream reads as "own stream":
+        it is addressed as hipStreamLegacy (the handle 1) instead."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        self.set_stream(stream.cuda_stream or 1)
 
     def update_camera(self, camera):
         """Camera change: new pose, accumulation cleared, sample counter back to 0

@@ -48,6 +48,7 @@ struct Tuning {
 	int acc_lds = -1;         // RTHIP_ACC_LDS: per-wave accumulation tiles in LDS: -1 = scenes with nothing below the root, 0 = never, 1 = wherever they fit
 	int threads = 0;          // RTHIP_THREADS: force the workgroup size (256, 512, 1024), 0 = most resident waves
 	int blocks_per_cu = 0;    // RTHIP_BLOCKS_PER_CU: cap on resident workgroups per CU, 0 = none
+	int grid_reserve = -1;    // RTHIP_GRID_RESERVE: workgroup slots of the chip a launch leaves empty (for kernels of other streams); -1 = none, or 1/16 of them with a multi-rank communicator
 	int chunk = 0;            // RTHIP_CHUNK: samples of a tile per work item, 0 = by launch size
 	int trav_threshold = -1;  // RTHIP_TRAV_THRESHOLD: -1 = 14 (scene in LDS) / 36 (global memory)
 	int inner_exit = -1;      // RTHIP_INNER_EXIT: sixteenths, -1 = 4 (LDS) / 8 (global memory)
@@ -64,6 +65,7 @@ struct Tuning {
 		t.acc_lds = env_int("RTHIP_ACC_LDS", t.acc_lds);
 		t.threads = env_int("RTHIP_THREADS", t.threads);
 		t.blocks_per_cu = env_int("RTHIP_BLOCKS_PER_CU", t.blocks_per_cu);
+		t.grid_reserve = env_int("RTHIP_GRID_RESERVE", t.grid_reserve);
 		t.chunk = env_int("RTHIP_CHUNK", t.chunk);
 		t.trav_threshold = env_int("RTHIP_TRAV_THRESHOLD", t.trav_threshold);
 		t.inner_exit = env_int("RTHIP_INNER_EXIT", t.inner_exit);
@@ -318,7 +320,14 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	const uint64_t my_paths = n_items * kTilePixels * chunk;
 	if (cap <= 0 && bpc >= 3 && my_paths < 512ull * (uint64_t)bpc * c->num_cu * waves_per_block) bpc = bpc * 2 / 3;
 	uint64_t want_blocks = (n_items + waves_per_block - 1) / waves_per_block;
-	plan->cfg.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc * c->num_cu, want_blocks));
+	// A launch that fills every workgroup slot of the chip keeps the kernels of other streams out until
+	// its tail (measured: a 50 MB add on a second stream finished 1.99 ms after the start of a 1.9 ms
+	// render, and 0.35 ms after it with 32 slots of 12 waves left empty).  The reduce that merges the
+	// GPUs' buffers is such a kernel and is meant to run under the next frame's tracing, so a context
+	// with a communicator of more than one rank leaves 1/16 of the chip's slots empty.
+	const uint64_t slots = (uint64_t)bpc * c->num_cu;
+	const uint64_t reserve = tune.grid_reserve >= 0 ? (uint64_t)tune.grid_reserve : (c->comm && c->comm_world > 1 ? slots / 16 : 0);
+	plan->cfg.grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(slots > reserve ? slots - reserve : 1, want_blocks));
 	// Leave the traversal loop for shading / regeneration once this few lanes are still in it.
 	// Measured optimum: 12-16 with the scene in LDS, about 36 when every node is a trip to L1 or L2.
 	plan->threshold = tune.trav_threshold >= 0 ? tune.trav_threshold : (in_lds ? 14 : 36);
@@ -598,6 +607,7 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		else if (k == "acc_lds") t.acc_lds = iv;
 		else if (k == "threads") t.threads = iv;
 		else if (k == "blocks_per_cu") t.blocks_per_cu = iv;
+		else if (k == "grid_reserve") t.grid_reserve = iv;
 		else if (k == "chunk") t.chunk = iv;
 		else if (k == "trav_threshold") t.trav_threshold = iv;
 		else if (k == "inner_exit") t.inner_exit = iv;

@@ -95,3 +95,28 @@ def test_rccl_reduce_of_one_rank(rt):
     with pytest.raises(rt.RthipError):
         r.merge_reduce(3)                      # not a rank of this communicator
     r.close()
+
+
+def test_reserved_slots_and_torch_default_stream(rt):
+    """A launch that leaves workgroup slots empty for the kernels of other streams (what a context
+    with a multi-rank communicator does) renders the same words; and a caller-owned buffer zeroed by
+    torch on its DEFAULT stream (handle 0) is ordered against renders through set_torch_stream."""
+    import torch
+    from raytracer_amd import distributed as D
+    sc = rt.Scene.generate("default")
+    cam = rt.Camera((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6, 640, 360)
+    ref = rt.Renderer(sc, cam, seed=SEED, max_depth=10)
+    ref.accumulate(SPP, spp_begin=0)
+    want = _words(ref)
+    ref.close()
+    r = rt.Renderer(sc, cam, seed=SEED, max_depth=10, options={"grid_reserve": 48})
+    r.set_torch_stream()                       # torch's current stream here is the default one
+    buf = D.new_accum_tensor(640, 360, "cuda:0")
+    r.set_accum_buffer(buf.data_ptr(), buf.numel())
+    for _ in range(3):                         # zero-fill and render back to back, no host waits in between
+        buf.zero_()
+        r.accumulate(SPP, spp_begin=0, sync=False)
+    torch.cuda.current_stream().synchronize()  # the renders are on that very stream
+    assert np.array_equal(buf.cpu().numpy().view(np.uint64), want)
+    r.set_accum_buffer(0, 0)
+    r.close()
