@@ -210,6 +210,8 @@ def main():
             return D.AbiMergePipeline(r, make, root=0)
         if multi:
             merge_kind["kind"] = "torch.distributed.reduce(SUM, int64) over RCCL"
+            if world > 1:
+                r.set_option("grid_reserve", 48)   # room for the reduce kernel under the next step's render (the ABI merge reserves it by itself)
         return D.MergePipeline(make, dst=0)
 
     def run_workload(name, steps, warmup, spp_override=0, precision=rt.F32):
