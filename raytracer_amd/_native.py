@@ -75,6 +75,7 @@ SYMBOLS = {
     "rthip_get_stats": (C.c_int32, [_P, C.POINTER(Stats)]),
     "rthip_bvh_leaf_order": (C.c_int32, [_P, C.c_int64, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "rthip_bvh_gate_count": (C.c_int32, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rthip_scene_validate": (C.c_int32, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rthip_bvh_validate": (C.c_int32, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "rthip_scene_generate": (C.c_int32, [C.c_char_p, C.c_uint32, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "rthip_camera_rotation": (None, [C.c_double, C.c_double, C.POINTER(C.c_double)]),

@@ -184,12 +184,21 @@ class Renderer:
         self.max_depth, self.seed, self.sky_mode, self.precision = max_depth, seed, sky_mode, precision
         self.variant = variant  # MEGAKERNEL (persistent threads) or WAVEFRONT (generate / extend / shade per bounce)
         self.spp_done = 0
+        self._upload(scene)
+        self.update_camera(camera)
+
+    def _upload(self, scene):
         objs = scene.objects if isinstance(scene, Scene) else scene.scene.objects
         self._objs = np.ascontiguousarray(objs, dtype=N.OBJECT_DTYPE)
         code = self._lib.rthip_scene_upload(self._ctx, self._objs.ctypes.data, len(self._objs))
         if code != N.OK:
             self._raise(code)
-        self.update_camera(camera)
+
+    def set_scene(self, scene):
+        """Another scene (or the same one under other build options) into this context: tree rebuilt,
+        accumulation cleared, camera kept."""
+        self._upload(scene)
+        self.reset_accumulation()
 
     def _raise(self, code):
         msg = self._lib.rthip_last_error(self._ctx)
@@ -264,6 +273,14 @@ class Renderer:
 
     def synchronize(self):
         self._check(self._lib.rthip_synchronize(self._ctx))
+
+    def validate_tree(self):
+        """Downloads the tree the device holds and checks it (rthip_scene_validate): every box
+        contains what is below it, every primitive is in exactly one leaf, depth as reported.
+        Returns (n_nodes, depth); raises with the first violation otherwise."""
+        bad, nodes, depth = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.rthip_scene_validate(self._ctx, C.byref(bad), C.byref(nodes), C.byref(depth)))
+        return nodes.value, depth.value
 
     def stats(self):
         s = N.Stats()

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <exception>
 #include <map>
@@ -14,6 +15,7 @@
 #include <vector>
 
 #include "../../include/rthip.h"
+#include "build_gpu.hpp"
 #include "comm.hpp"
 #include "host.hpp"
 #include "launch.hpp"
@@ -32,6 +34,13 @@ struct SceneBlob {  // one precision of the scene in HBM: [nodes | prims | mats]
 	QFrame qframe{};
 };
 inline uint32_t align_up(uint64_t v, uint32_t a) { return (uint32_t)((v + a - 1) / a * a); }
+
+// The entry points that work without a context build on the host alone.
+BuildOptions host_only_options() {
+	BuildOptions o = BuildOptions::from_env();
+	o.tree_gpu = false;
+	return o;
+}
 
 int env_int(const char* name, int dflt) {
 	const char* v = std::getenv(name);
@@ -89,6 +98,7 @@ struct rthip_ctx {
 	bool has_scene = false, has_camera = false;
 	SceneBlob blob32, blob64;
 	int tree_depth = 0, n_nodes = 0, n_leaves = 0, n_prims = 0, n_gates = 0;
+	int64_t n_objects = 0;
 	int32_t big_leaf = 0, start = 0;  // leaf of oversized primitives tested at ray start, and the tree's entry after it
 
 	CameraFields cam{};
@@ -616,6 +626,8 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		else if (k == "wf_batch") t.wf_batch = iv;
 		else if (k == "count") t.count = iv;
 		else if (k == "tree_ref") b.tree_ref = iv != 0;
+		else if (k == "tree_gpu") b.tree_gpu = iv != 0;
+		else if (k == "gpu_leaf") b.gpu_leaf = iv;
 		else if (k == "sah_leaf") b.sah_leaf = iv;
 		else if (k == "sah_cprim") b.sah_cprim = value;
 		else if (k == "sah_sweep") b.sah_sweep = iv;
@@ -644,9 +656,31 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 		if (rc != RTHIP_OK) return rc;
 		rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
 		if (rc != RTHIP_OK) return rc;
+		if (flat.gpu.on) {
+			// the tree over the laid-out primitives is built on the device (build_gpu.hip)
+			const FlatScene::GpuPlan& g = flat.gpu;
+			GpuBuildIO io{};
+			io.blob32 = c->blob32.dev; io.blob64 = c->blob64.dev;
+			io.prims_off32 = c->blob32.prims_off; io.mats_off32 = c->blob32.mats_off; io.qnodes_off32 = c->blob32.qnodes_off;
+			io.prims_off64 = c->blob64.prims_off; io.mats_off64 = c->blob64.mats_off;
+			io.first = g.first; io.count = g.count; io.leaf_size = g.leaf_size; io.n_leaves = g.n_leaves; io.node_base = g.node_base;
+			io.n_nodes = (int32_t)flat.nodes32.size();
+			for (int k = 0; k < 3; k++) { io.clo[k] = g.clo[k]; io.cinv[k] = g.cinv[k]; }
+			io.quantise = g.quantise && c->blob32.qnodes_off != 0;
+			GpuBuildResult res{};
+			const auto t0 = std::chrono::steady_clock::now();
+			HIP_TRY(c, gpu_build_tree(io, c->stream, &res));
+			if (c->build_opt.timing)
+				std::fprintf(stderr, "[rthip build] %-28s %.3f s\n", "device tree (on the GPU)", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+			flat.depth = std::max(1, res.levels + g.node_base);
+			if (flat.depth > kStackMax) return fail(c, RTHIP_ERR_LIMIT, "tree deeper than the traversal stack (device build: " + std::to_string(flat.depth) + " levels)");
+			if (res.quantised) { c->blob32.qframe = res.frame; c->blob32.qframe.big_leaf = flat.big_leaf; }
+			else c->blob32.qnodes_off = 0;
+		}
 		c->big_leaf = flat.big_leaf; c->start = flat.start;
 		c->tree_depth = flat.depth; c->n_nodes = (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)flat.prims32.size();
 		c->n_gates = (int)flat.gates32.size();
+		c->n_objects = n;
 		c->stats.n_nodes = c->n_nodes; c->stats.n_leaves = c->n_leaves; c->stats.n_prims = c->n_prims; c->stats.tree_depth = c->tree_depth;
 		c->stats.n_gates = c->n_gates;
 		c->has_scene = true;
@@ -1069,7 +1103,7 @@ int32_t rthip_bvh_leaf_order(const rthip_object* objects, int64_t n, int32_t* id
 		if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
 		FlatScene flat;
 		std::string err;
-		if (!build_flat_scene(objects, n, &flat, &err, BuildOptions::from_env())) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+		if (!build_flat_scene(objects, n, &flat, &err, host_only_options())) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
 		if (ids) std::copy(flat.leaf_ids.begin(), flat.leaf_ids.end(), ids);
 		if (leaf_sizes) std::copy(flat.leaf_sizes.begin(), flat.leaf_sizes.end(), leaf_sizes);
 		if (n_leaves) *n_leaves = (int64_t)flat.leaf_sizes.size();
@@ -1084,7 +1118,7 @@ int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* viol
 		if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
 		FlatScene flat;
 		std::string err;
-		if (!build_flat_scene(objects, n, &flat, &err, BuildOptions::from_env())) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+		if (!build_flat_scene(objects, n, &flat, &err, host_only_options())) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
 		std::string first;
 		const int64_t bad = validate_flat_scene(flat, n, &first);
 		if (violations) *violations = bad;
@@ -1096,13 +1130,42 @@ int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* viol
 	});
 }
 
+int32_t rthip_scene_validate(rthip_ctx* c, int64_t* violations, int32_t* n_nodes, int32_t* depth) {
+	if (!c) return RTHIP_ERR_INVALID;
+	return guarded(c, [&]() -> int32_t {
+		if (!c->has_scene) return fail(c, RTHIP_ERR_STATE, "upload a scene first");
+		HIP_TRY(c, hipSetDevice(c->device));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		FlatScene s;
+		s.nodes32.resize((size_t)c->n_nodes); s.nodes64.resize((size_t)c->n_nodes);
+		s.prims32.resize((size_t)c->n_prims); s.prims64.resize((size_t)c->n_prims);
+		HIP_TRY(c, hipMemcpy(s.nodes32.data(), c->blob32.dev, s.nodes32.size() * sizeof(Node<float>), hipMemcpyDeviceToHost));
+		HIP_TRY(c, hipMemcpy(s.nodes64.data(), c->blob64.dev, s.nodes64.size() * sizeof(Node<double>), hipMemcpyDeviceToHost));
+		HIP_TRY(c, hipMemcpy(s.prims32.data(), c->blob32.dev + c->blob32.prims_off, s.prims32.size() * sizeof(Prim<float>), hipMemcpyDeviceToHost));
+		HIP_TRY(c, hipMemcpy(s.prims64.data(), c->blob64.dev + c->blob64.prims_off, s.prims64.size() * sizeof(Prim<double>), hipMemcpyDeviceToHost));
+		if (c->blob32.qnodes_off) {
+			s.qnodes.resize((size_t)c->n_nodes);
+			HIP_TRY(c, hipMemcpy(s.qnodes.data(), c->blob32.dev + c->blob32.qnodes_off, s.qnodes.size() * sizeof(QNode), hipMemcpyDeviceToHost));
+			s.qframe = c->blob32.qframe;
+		}
+		s.big_leaf = c->big_leaf; s.start = c->start; s.depth = c->tree_depth;
+		std::string first;
+		const int64_t bad = validate_flat_scene(s, c->n_objects, &first);
+		if (violations) *violations = bad;
+		if (n_nodes) *n_nodes = c->n_nodes;
+		if (depth) *depth = c->tree_depth;
+		if (bad) return fail(c, RTHIP_ERR_STATE, first);
+		return RTHIP_OK;
+	});
+}
+
 int32_t rthip_bvh_gate_count(const rthip_object* objects, int64_t n, int64_t* n_gates, int64_t* n_gated_spheres) {
 	return guarded(nullptr, [&]() -> int32_t {
 		if (n < 0 || (n > 0 && !objects)) return fail(nullptr, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
 		if (n == 0) return fail(nullptr, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
 		FlatScene flat;
 		std::string err;
-		if (!build_flat_scene(objects, n, &flat, &err, BuildOptions::from_env())) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+		if (!build_flat_scene(objects, n, &flat, &err, host_only_options())) return fail(nullptr, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
 		int64_t gated = 0;
 		for (const Prim<float>& p : flat.prims32)
 			if (((p.id >> kKindShift) & 1) == RTHIP_SPHERE && prim_gate_count(p) != 0) gated++;

@@ -1,0 +1,349 @@
+// build_gpu.hip — the device tree built ON the GPU (build option "tree_gpu").
+//
+// The reference builds its tree on the host by recursive median splits (src/bvh.rs:17-81).  The
+// closest hit does not depend on the tree that finds it (tie ranks and gates carry what the
+// reference's own tree decides, see host.cpp), so the tree the kernels walk may come from any
+// builder.  This one is a linear BVH: Morton codes of the primitive centres, one radix sort,
+// leaves of `leaf_size` consecutive primitives, the hierarchy over the leaves' codes found by
+// every inner node on its own (Karras 2012), and a bottom-up pass that unions boxes, the second
+// child to arrive carrying on.  It is for scenes that change from frame to frame: a million
+// primitives take a few milliseconds, where the host's surface-area build takes a quarter of a
+// second; the tree is coarser and traces slower than that one.
+//
+// Input, already in the scene blobs (both precisions): the primitives [first, first + count) in
+// any order and their materials in the same order; node_base + n_leaves - 1 zeroed nodes.
+// Output: the primitives and materials permuted into leaf order (spheres before cubes inside a
+// leaf), nodes [node_base, node_base + n_leaves - 1) with inner node 0 of the hierarchy at
+// node_base, and, when node_base is 1, the right child of node 0 (whose left child, the leaf of
+// oversized primitives, the host has written).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "build_gpu.hpp"
+
+namespace rthip {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLoSlot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, kHiSlot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+
+struct Box6 { double lo[3], hi[3]; };
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {  // bit i -> bit 3 i
+	v &= 0x1fffffull;
+	v = (v | v << 32) & 0x1f00000000ffffull;
+	v = (v | v << 16) & 0x1f0000ff0000ffull;
+	v = (v | v << 8) & 0x100f00f00f00f00full;
+	v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+	v = (v | v << 2) & 0x1249249249249249ull;
+	return v;
+}
+
+// 63-bit Morton code of every primitive's centre inside the box of all centres.
+__global__ void codes_kernel(GpuBuildIO io, unsigned long long* keys, uint32_t* vals) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= (uint32_t)io.count) return;
+	const Prim<double>* prims = reinterpret_cast<const Prim<double>*>(io.blob64 + io.prims_off64);
+	const Prim<double>& p = prims[io.first + i];
+	unsigned long long code = 0;
+	for (int k = 0; k < 3; k++) {
+		double u = (p.v[k] - io.clo[k]) * io.cinv[k];  // the centre: slots 0..2 of spheres and of f64 cubes
+		u = fmin(fmax(u, 0.0), 1.0);
+		code |= spread21((unsigned long long)(u * 2097151.0)) << (2 - k);
+	}
+	keys[i] = code;
+	vals[i] = i;
+}
+
+// Bounds of a primitive as each precision stores it (host.cpp bounds64 / bounds32).
+__device__ __forceinline__ void prim_bounds(const Prim<double>& p64, const Prim<float>& p32, Box6* b64, Box6* b32) {
+	const bool sphere = ((p64.id >> kKindShift) & 1) == RTHIP_SPHERE;
+	for (int k = 0; k < 3; k++) {
+		const double e = fabs(sphere ? p64.v[3] : p64.v[3 + k]);
+		b64->lo[k] = p64.v[k] - e; b64->hi[k] = p64.v[k] + e;
+		if (sphere) {
+			const double c = (double)p32.v[k], r = fabs((double)p32.v[3]);
+			b32->lo[k] = c - r; b32->hi[k] = c + r;
+		} else {
+			const double lo = (double)p32.v[kLoSlot[k]], hi = (double)p32.v[kHiSlot[k]];
+			b32->lo[k] = fmin(lo, hi); b32->hi[k] = fmax(lo, hi);
+		}
+	}
+}
+__device__ __forceinline__ void box_join(Box6* a, const Box6& b) {
+	for (int k = 0; k < 3; k++) { a->lo[k] = fmin(a->lo[k], b.lo[k]); a->hi[k] = fmax(a->hi[k], b.hi[k]); }
+}
+
+// One thread per leaf: moves its primitives and materials into place (spheres first), writes the
+// leaf's code, key and boxes.
+__global__ void leaves_kernel(GpuBuildIO io, const unsigned long long* keys, const uint32_t* vals,
+                              const Prim<float>* in_p32, const Prim<double>* in_p64, const Mat<float>* in_m32, const Mat<double>* in_m64,
+                              int32_t* leaf_codes, unsigned long long* leaf_keys, Box6* leaf_b64, Box6* leaf_b32) {
+	const uint32_t leaf = blockIdx.x * kBlock + threadIdx.x;
+	if (leaf >= (uint32_t)io.n_leaves) return;
+	Prim<float>* p32 = reinterpret_cast<Prim<float>*>(io.blob32 + io.prims_off32);
+	Prim<double>* p64 = reinterpret_cast<Prim<double>*>(io.blob64 + io.prims_off64);
+	Mat<float>* m32 = reinterpret_cast<Mat<float>*>(io.blob32 + io.mats_off32);
+	Mat<double>* m64 = reinterpret_cast<Mat<double>*>(io.blob64 + io.mats_off64);
+	const uint32_t j0 = leaf * (uint32_t)io.leaf_size, j1 = min((uint32_t)io.count, j0 + (uint32_t)io.leaf_size);
+	Box6 b64, b32;
+	for (int k = 0; k < 3; k++) { b64.lo[k] = b32.lo[k] = DBL_MAX; b64.hi[k] = b32.hi[k] = -DBL_MAX; }
+	uint32_t pos = (uint32_t)io.first + j0;
+	int ns = 0, nc = 0;
+	for (int pass = 0; pass < 2; pass++) {
+		for (uint32_t j = j0; j < j1; j++) {
+			const uint32_t src = vals[j];  // index into the unsorted copies
+			const Prim<double> q64 = in_p64[src];
+			const bool sphere = ((q64.id >> kKindShift) & 1) == RTHIP_SPHERE;
+			if (sphere != (pass == 0)) continue;
+			const Prim<float> q32 = in_p32[src];
+			p64[pos] = q64; p32[pos] = q32;
+			m64[pos] = in_m64[src]; m32[pos] = in_m32[src];
+			Box6 a64, a32;
+			prim_bounds(q64, q32, &a64, &a32);
+			box_join(&b64, a64); box_join(&b32, a32);
+			pos++;
+			if (sphere) ns++; else nc++;
+		}
+	}
+	leaf_codes[leaf] = leaf_code((int32_t)((uint32_t)io.first + j0), ns, nc);
+	leaf_keys[leaf] = keys[j0];
+	leaf_b64[leaf] = b64; leaf_b32[leaf] = b32;
+}
+
+// Length of the common prefix of the keys of leaves i and j, the leaf index breaking ties.
+__device__ __forceinline__ int prefix(const unsigned long long* keys, int n, int i, int j) {
+	if (j < 0 || j >= n) return -1;
+	const unsigned long long a = keys[i], b = keys[j];
+	if (a == b) return 64 + __clz((unsigned)(i ^ j));
+	return __clzll((long long)(a ^ b));
+}
+
+// One thread per inner node: its range of leaves and where that range splits (Karras 2012).
+// parent_*: index of the parent inner node, bit 31 set for "I am its right child"; the root has -1.
+__global__ void hierarchy_kernel(GpuBuildIO io, const unsigned long long* keys, const int32_t* leaf_codes, int32_t* parent_inner, int32_t* parent_leaf) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	const int n = io.n_leaves;
+	if (i >= n - 1) return;
+	const int d = prefix(keys, n, i, i + 1) - prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
+	const int dmin = prefix(keys, n, i, i - d);
+	int lmax = 2;
+	while (prefix(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+	int l = 0;
+	for (int t = lmax / 2; t >= 1; t /= 2)
+		if (prefix(keys, n, i, i + (l + t) * d) > dmin) l += t;
+	const int j = i + l * d;
+	const int dnode = prefix(keys, n, i, j);
+	int s = 0, t = l;
+	do {
+		t = (t + 1) / 2;
+		if (prefix(keys, n, i, i + (s + t) * d) > dnode) s += t;
+	} while (t > 1);
+	const int gamma = i + s * d + min(d, 0);
+	const int lo = min(i, j), hi = max(i, j);
+	Node<float>* n32 = reinterpret_cast<Node<float>*>(io.blob32);
+	Node<double>* n64 = reinterpret_cast<Node<double>*>(io.blob64);
+	int32_t child[2];
+	if (lo == gamma) { child[0] = leaf_codes[gamma]; parent_leaf[gamma] = i; }
+	else { child[0] = io.node_base + gamma; parent_inner[gamma] = i; }
+	if (hi == gamma + 1) { child[1] = leaf_codes[gamma + 1]; parent_leaf[gamma + 1] = i | (int32_t)0x80000000; }
+	else { child[1] = io.node_base + gamma + 1; parent_inner[gamma + 1] = i | (int32_t)0x80000000; }
+	for (int c = 0; c < 2; c++) { n32[io.node_base + i].child[c] = child[c]; n64[io.node_base + i].child[c] = child[c]; }
+	if (i == 0) parent_inner[0] = -1;
+}
+
+// A child's box into its parent's node, in the forms the kernels read (host.cpp write_node): f64
+// as planes; f32 as centre and half extent, the half extent taken from the rounded centre, widened
+// by 2^-20 and rounded up.
+__device__ __forceinline__ float float_at_least(double x) {  // smallest float >= x, for x > 0
+	float f = (float)x;
+	if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + 1u);
+	return f;
+}
+__device__ __forceinline__ void store_child_box(Node<float>* n32, Node<double>* n64, int side, const Box6& b64, const Box6& b32) {
+	for (int k = 0; k < 3; k++) {
+		n64->box[6 * side + kLoSlot[k]] = b64.lo[k];
+		n64->box[6 * side + kHiSlot[k]] = b64.hi[k];
+		const double lo = b32.lo[k], hi = b32.hi[k];
+		if (lo <= hi) {
+			const float centre = (float)(0.5 * lo + 0.5 * hi);
+			const double half = fmax(hi - (double)centre, (double)centre - lo);
+			n32->box[6 * side + kLoSlot[k]] = centre;
+			n32->box[6 * side + kHiSlot[k]] = float_at_least(half * (1.0 + 0x1p-20) + 1e-37);
+		} else {
+			n32->box[6 * side + kLoSlot[k]] = 0.0f;
+			n32->box[6 * side + kHiSlot[k]] = -1e30f;
+		}
+	}
+}
+__device__ __forceinline__ double load_coherent(const double* p) {  // written by another workgroup: read at the L2
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One thread per leaf climbs towards the root; at every inner node the first child to arrive
+// stops, the second unions both boxes and goes on.  side_b32[2 * node + side] keeps the f32-side
+// bounds as planes (the node itself holds them as centre and half extent, which cannot be
+// unioned exactly).  Also counts the inner nodes above each leaf: the deepest count is the
+// traversal stack a ray can need.
+__global__ void fit_kernel(GpuBuildIO io, const int32_t* parent_inner, const int32_t* parent_leaf, const Box6* leaf_b64, const Box6* leaf_b32,
+                           Box6* side_b32, uint32_t* arrived, int32_t* deepest) {
+	const uint32_t leaf = blockIdx.x * kBlock + threadIdx.x;
+	if (leaf >= (uint32_t)io.n_leaves) return;
+	Node<float>* n32 = reinterpret_cast<Node<float>*>(io.blob32);
+	Node<double>* n64 = reinterpret_cast<Node<double>*>(io.blob64);
+	{
+		int levels = 0;
+		for (int32_t p = parent_leaf[leaf]; p != -1; p = parent_inner[p & 0x7fffffff]) levels++;
+		atomicMax(deepest, levels);
+	}
+	Box6 b64 = leaf_b64[leaf], b32 = leaf_b32[leaf];
+	int32_t p = parent_leaf[leaf];
+	for (;;) {
+		const int node = p & 0x7fffffff, side = (p >> 31) & 1;
+		store_child_box(&n32[io.node_base + node], &n64[io.node_base + node], side, b64, b32);
+		side_b32[2 * node + side] = b32;
+		__threadfence();
+		if (atomicAdd(&arrived[node], 1u) == 0u) return;  // the sibling is still on its way: it will carry on
+		__threadfence();
+		const Node<double>* me64 = &n64[io.node_base + node];
+		const Box6* other32 = &side_b32[2 * node + (1 - side)];
+		for (int k = 0; k < 3; k++) {
+			b64.lo[k] = fmin(b64.lo[k], load_coherent(&me64->box[6 * (1 - side) + kLoSlot[k]]));
+			b64.hi[k] = fmax(b64.hi[k], load_coherent(&me64->box[6 * (1 - side) + kHiSlot[k]]));
+			b32.lo[k] = fmin(b32.lo[k], load_coherent(&other32->lo[k]));
+			b32.hi[k] = fmax(b32.hi[k], load_coherent(&other32->hi[k]));
+		}
+		p = parent_inner[node];
+		if (p == -1) {
+			// the root of the hierarchy: with a leaf of oversized primitives beside it, node 0 holds
+			// that leaf on the left and this tree on the right
+			if (io.node_base == 1) {
+				store_child_box(&n32[0], &n64[0], 1, b64, b32);
+				n32[0].child[1] = n64[0].child[1] = io.node_base;
+			}
+			return;
+		}
+	}
+}
+
+// Quantised copy of the f32 nodes (QNode, layout.hpp; host.cpp does the same for its own trees):
+// planes in steps of the frame's grid, rounded outward by at least a step.
+__global__ void quantise_kernel(GpuBuildIO io, QFrame f, int32_t first_node, int* overflow) {
+	const int i = first_node + (int)(blockIdx.x * kBlock + threadIdx.x);
+	if (i >= io.n_nodes) return;
+	const Node<float>& n = reinterpret_cast<const Node<float>*>(io.blob32)[i];
+	QNode q;
+	for (int c = 0; c < 2; c++) {
+		for (int k = 0; k < 3; k++) {
+			const float centre = n.box[6 * c + kLoSlot[k]], half = n.box[6 * c + kHiSlot[k]];
+			if (half < 0.0f) { q.q[6 * c + kLoSlot[k]] = kQMax; q.q[6 * c + kHiSlot[k]] = 0; continue; }  // empty box
+			const double l = (double)centre - (double)half, h = (double)centre + (double)half;
+			double ql = floor((l - (double)f.centre[k]) / (double)f.step[k]) - 1.0;
+			double qh = ceil((h - (double)f.centre[k]) / (double)f.step[k]) + 1.0;
+			if (ql < -kQMax || qh > kQMax) *overflow = 1;
+			ql = fmax(ql, (double)-kQMax); qh = fmin(qh, (double)kQMax);
+			q.q[6 * c + kLoSlot[k]] = (int16_t)ql;
+			q.q[6 * c + kHiSlot[k]] = (int16_t)(uint16_t)(qh - ql);
+		}
+		q.child[c] = n.child[c];
+	}
+	reinterpret_cast<QNode*>(io.blob32 + io.qnodes_off32)[i] = q;
+}
+
+struct Scratch {  // device memory of one build, freed when it goes out of scope
+	std::vector<void*> ptrs;
+	~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+	template <typename T> hipError_t get(T** out, size_t n) {
+		void* p = nullptr;
+		hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+		if (e != hipSuccess) return e;
+		ptrs.push_back(p);
+		*out = static_cast<T*>(p);
+		return hipSuccess;
+	}
+};
+
+#define GB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+}  // namespace
+
+hipError_t gpu_build_tree(const GpuBuildIO& io_in, hipStream_t stream, GpuBuildResult* res) {
+	GpuBuildIO io = io_in;
+	if (io.count < 2 || io.leaf_size < 1 || io.leaf_size > 7 || io.n_leaves != (io.count + io.leaf_size - 1) / io.leaf_size || io.n_leaves < 2 ||
+	    io.n_nodes != io.node_base + io.n_leaves - 1 || (io.node_base != 0 && io.node_base != 1))
+		return hipErrorInvalidValue;
+	Scratch mem;
+	const size_t n = (size_t)io.count, nl = (size_t)io.n_leaves;
+	unsigned long long *keys_a, *keys_b, *leaf_keys;
+	uint32_t *vals_a, *vals_b, *arrived;
+	Prim<float>* in_p32; Prim<double>* in_p64; Mat<float>* in_m32; Mat<double>* in_m64;
+	int32_t *leaf_codes, *parent_inner, *parent_leaf, *deepest;
+	Box6 *leaf_b64, *leaf_b32, *side_b32;
+	int* overflow;
+	GB_TRY(mem.get(&keys_a, n)); GB_TRY(mem.get(&keys_b, n)); GB_TRY(mem.get(&vals_a, n)); GB_TRY(mem.get(&vals_b, n));
+	GB_TRY(mem.get(&in_p32, n)); GB_TRY(mem.get(&in_p64, n)); GB_TRY(mem.get(&in_m32, n)); GB_TRY(mem.get(&in_m64, n));
+	GB_TRY(mem.get(&leaf_codes, nl)); GB_TRY(mem.get(&leaf_keys, nl)); GB_TRY(mem.get(&leaf_b64, nl)); GB_TRY(mem.get(&leaf_b32, nl));
+	GB_TRY(mem.get(&parent_inner, nl)); GB_TRY(mem.get(&parent_leaf, nl)); GB_TRY(mem.get(&side_b32, 2 * nl)); GB_TRY(mem.get(&arrived, nl));
+	GB_TRY(mem.get(&deepest, 1)); GB_TRY(mem.get(&overflow, 1));
+	GB_TRY(hipMemsetAsync(arrived, 0, nl * sizeof(uint32_t), stream));
+	GB_TRY(hipMemsetAsync(deepest, 0, sizeof(int32_t), stream));
+	GB_TRY(hipMemsetAsync(overflow, 0, sizeof(int), stream));
+	// the unsorted primitives and materials, aside: the scene blobs receive them in leaf order
+	GB_TRY(hipMemcpyAsync(in_p32, io.blob32 + io.prims_off32 + (size_t)io.first * sizeof(Prim<float>), n * sizeof(Prim<float>), hipMemcpyDeviceToDevice, stream));
+	GB_TRY(hipMemcpyAsync(in_p64, io.blob64 + io.prims_off64 + (size_t)io.first * sizeof(Prim<double>), n * sizeof(Prim<double>), hipMemcpyDeviceToDevice, stream));
+	GB_TRY(hipMemcpyAsync(in_m32, io.blob32 + io.mats_off32 + (size_t)io.first * sizeof(Mat<float>), n * sizeof(Mat<float>), hipMemcpyDeviceToDevice, stream));
+	GB_TRY(hipMemcpyAsync(in_m64, io.blob64 + io.mats_off64 + (size_t)io.first * sizeof(Mat<double>), n * sizeof(Mat<double>), hipMemcpyDeviceToDevice, stream));
+	const unsigned grid_p = (unsigned)((n + kBlock - 1) / kBlock), grid_l = (unsigned)((nl + kBlock - 1) / kBlock);
+	hipLaunchKernelGGL(codes_kernel, dim3(grid_p), dim3(kBlock), 0, stream, io, keys_a, vals_a);
+	GB_TRY(hipGetLastError());
+	size_t temp_bytes = 0;
+	GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, stream));
+	char* temp;
+	GB_TRY(mem.get(&temp, temp_bytes));
+	GB_TRY(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, stream));
+	hipLaunchKernelGGL(leaves_kernel, dim3(grid_l), dim3(kBlock), 0, stream, io, keys_b, vals_b, in_p32, in_p64, in_m32, in_m64, leaf_codes, leaf_keys, leaf_b64, leaf_b32);
+	GB_TRY(hipGetLastError());
+	hipLaunchKernelGGL(hierarchy_kernel, dim3(grid_l), dim3(kBlock), 0, stream, io, leaf_keys, leaf_codes, parent_inner, parent_leaf);
+	GB_TRY(hipGetLastError());
+	hipLaunchKernelGGL(fit_kernel, dim3(grid_l), dim3(kBlock), 0, stream, io, parent_inner, parent_leaf, leaf_b64, leaf_b32, side_b32, arrived, deepest);
+	GB_TRY(hipGetLastError());
+	int32_t levels = 0;
+	Node<float> node0;
+	GB_TRY(hipMemcpyAsync(&levels, deepest, sizeof(levels), hipMemcpyDeviceToHost, stream));
+	GB_TRY(hipMemcpyAsync(&node0, io.blob32, sizeof(node0), hipMemcpyDeviceToHost, stream));
+	GB_TRY(hipStreamSynchronize(stream));
+	res->levels = levels;
+	res->quantised = false;
+	if (io.quantise) {
+		// the grid spans the tree's own bounds (the leaf of oversized primitives stays outside it)
+		QFrame& f = res->frame;
+		for (int k = 0; k < 3; k++) {
+			double lo = DBL_MAX, hi = -DBL_MAX;
+			for (int c = (io.node_base == 1 ? 1 : 0); c < 2; c++) {
+				const float centre = node0.box[6 * c + kLoSlot[k]], half = node0.box[6 * c + kHiSlot[k]];
+				if (half < 0.0f) continue;
+				lo = std::fmin(lo, (double)centre - (double)half); hi = std::fmax(hi, (double)centre + (double)half);
+			}
+			f.centre[k] = (float)(0.5 * (lo + hi));
+			const double half = std::fmax(hi - (double)f.centre[k], (double)f.centre[k] - lo);
+			f.step[k] = (float)std::fmax(half / (kQMax - 64), 1e-30);  // headroom for the outward rounding
+		}
+		f.start = io.node_base;
+		f.big_leaf = 0;  // the caller knows the leaf's code
+		const int first_node = io.node_base;
+		hipLaunchKernelGGL(quantise_kernel, dim3((unsigned)((io.n_nodes - first_node + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, io, f, first_node, overflow);
+		GB_TRY(hipGetLastError());
+		int over = 0;
+		GB_TRY(hipMemcpyAsync(&over, overflow, sizeof(over), hipMemcpyDeviceToHost, stream));
+		GB_TRY(hipStreamSynchronize(stream));
+		res->quantised = over == 0;
+	}
+	return hipSuccess;
+}
+
+}  // namespace rthip

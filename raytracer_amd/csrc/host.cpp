@@ -757,7 +757,8 @@ struct Builder {
 
 BuildOptions BuildOptions::from_env() {
 	BuildOptions o;
-	if (const char* v = std::getenv("RTHIP_TREE")) o.tree_ref = std::string(v) == "ref";
+	if (const char* v = std::getenv("RTHIP_TREE")) { o.tree_ref = std::string(v) == "ref"; o.tree_gpu = std::string(v) == "gpu"; }
+	if (const char* v = std::getenv("RTHIP_GPU_LEAF")) o.gpu_leaf = std::atoi(v);
 	if (const char* v = std::getenv("RTHIP_SAH_LEAF")) o.sah_leaf = std::atoi(v);
 	if (const char* v = std::getenv("RTHIP_SAH_CPRIM")) o.sah_cprim = std::atof(v);
 	if (const char* v = std::getenv("RTHIP_SAH_SWEEP")) o.sah_sweep = std::atoi(v);
@@ -837,7 +838,58 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	Builder::Sub l, r;
 	r.code = leaf_code(0, 0, 0);
 	r.b64 = r.b32 = empty_box();
-	if (use_sah) {
+	// 2a. tree_gpu: lay the primitives out and leave the tree to the device
+	if (opt.tree_gpu) {
+		const int leaf_size = std::max(1, std::min(7, opt.gpu_leaf));
+		std::vector<int32_t> rest, big;
+		for (int64_t i = 0; i < n; i++) if (b.can_be_hit((int32_t)i)) rest.push_back((int32_t)i);
+		// the same few oversized primitives the surface-area build keeps out of its tree
+		auto diag = [&](int32_t id) {
+			Box bb = b.bounds64(id);
+			double dx = bb.hi[0] - bb.lo[0], dy = bb.hi[1] - bb.lo[1], dz = bb.hi[2] - bb.lo[2];
+			return std::sqrt(dx * dx + dy * dy + dz * dz);
+		};
+		if (rest.size() > (size_t)std::max(0, opt.big_leaf_min) && !opt.no_big_leaf) {
+			std::vector<double> d(rest.size());
+			for (size_t i = 0; i < rest.size(); i++) d[i] = diag(rest[i]);
+			std::nth_element(d.begin(), d.begin() + (long)(d.size() / 2), d.end());
+			const double limit = 64.0 * d[d.size() / 2];
+			int ns = 0, nc = 0;
+			for (int32_t id : rest) if (diag(id) > limit) { big.push_back(id); (objs[id].kind == RTHIP_SPHERE ? ns : nc)++; }
+			if (ns > 7 || nc > 7) big.clear();
+			if (!big.empty()) rest.erase(std::remove_if(rest.begin(), rest.end(), [&](int32_t id) { return diag(id) > limit; }), rest.end());
+		}
+		const size_t n_leaves = (rest.size() + (size_t)leaf_size - 1) / (size_t)leaf_size;
+		if (n_leaves >= 2) {
+			FlatScene::GpuPlan& g = out->gpu;
+			g.on = true;
+			g.leaf_size = leaf_size;
+			g.n_leaves = (int32_t)n_leaves;
+			g.node_base = big.empty() ? 0 : 1;
+			const size_t n_nodes = (size_t)g.node_base + n_leaves - 1;
+			out->nodes64.assign(n_nodes, Node<double>{});
+			out->nodes32.assign(n_nodes, Node<float>{});
+			if (!big.empty()) {
+				Builder::Sub bl = b.emit_leaf(big.data(), (int)big.size());
+				b.write_node(0, bl, r);  // the right child is the device's to fill in
+				out->big_leaf = bl.code;
+				out->start = 1;
+			}
+			g.first = (int32_t)out->prims64.size();
+			g.count = (int32_t)rest.size();
+			(void)b.emit_leaf(rest.data(), (int)rest.size());  // every other primitive, spheres then cubes, in object order
+			double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+			for (int32_t id : rest)
+				for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], objs[id].center[k]); hi[k] = std::fmax(hi[k], objs[id].center[k]); }
+			for (int k = 0; k < 3; k++) { g.clo[k] = lo[k]; g.cinv[k] = hi[k] > lo[k] ? 1.0 / (hi[k] - lo[k]) : 0.0; }
+			g.quantise = n_nodes > 2048 && !opt.no_qnodes;
+			if (g.quantise) out->qnodes.assign(n_nodes, QNode{});
+			lap("layout for the device build");
+		}
+	}
+	if (out->gpu.on) {
+		// nothing more to build here
+	} else if (use_sah) {
 		auto attempt = [&](double cost_prim) {
 			out->nodes64.clear(); out->nodes32.clear(); out->prims64.clear(); out->prims32.clear();
 			b.items.clear();
@@ -964,6 +1016,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		out->mats32.swap(m32);
 		out->mats64.swap(m64);
 	}
+	if (out->gpu.on) return true;  // depth, start and the quantised nodes come from the device build
 	out->depth = std::max(1, b.max_depth);
 	if (use_sah && !big_ids_empty) { out->big_leaf = out->nodes32[0].child[0]; out->start = out->nodes32[0].child[1]; }
 	if (out->depth > kStackMax) { *err = "tree deeper than the traversal stack"; return false; }

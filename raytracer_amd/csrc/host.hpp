@@ -43,12 +43,24 @@ struct FlatScene {
 	int n_leaves = 0;
 	std::vector<int32_t> leaf_ids;    // reference tree: object ids, leaves left to right, reference order inside a leaf
 	std::vector<int32_t> leaf_sizes;
+	// Build option tree_gpu: the host has laid out the primitives (the leaf of oversized ones first, in
+	// leaf order; the rest in object order), reserved the nodes and written node 0's left child if
+	// there is such a leaf; the tree over primitives [first, first + count) is built on the device
+	// (build_gpu.hpp), which also fills in depth, start and the quantised nodes.
+	struct GpuPlan {
+		bool on = false;
+		int32_t first = 0, count = 0, leaf_size = 4, n_leaves = 0, node_base = 0;
+		double clo[3] = {0, 0, 0}, cinv[3] = {0, 0, 0};  // box of the primitive centres: low corner, 1 / extent
+		bool quantise = false;
+	} gpu;
 };
 // Knobs of the host build.  A context reads them from the RTHIP_* environment ONCE, when it is
 // created (rthip_set_option changes them afterwards); the host-only entry points, which have no
 // context, read the environment per call.
 struct BuildOptions {
 	bool tree_ref = false;     // RTHIP_TREE=ref: the device tree keeps the reference's shape (default: surface-area build)
+	bool tree_gpu = false;     // RTHIP_TREE=gpu: the device tree is a linear BVH built on the GPU (scenes of at least two leaves; contexts only)
+	int gpu_leaf = 4;          // RTHIP_GPU_LEAF: primitives per leaf of that build, 1..7
 	int sah_leaf = 4;          // RTHIP_SAH_LEAF: largest leaf of the surface-area build, 1..7
 	double sah_cprim = -1.0;   // RTHIP_SAH_CPRIM: cost of a primitive test against a node visit; < 0 = chosen per scene
 	int sah_sweep = -1;        // RTHIP_SAH_SWEEP: exact sweep up to this many primitives per range; < 0 = chosen per scene

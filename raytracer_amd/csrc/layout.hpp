@@ -16,7 +16,7 @@ namespace rthip {
 
 constexpr int kTile = 8;              // tiles are 8x8 pixels = one wave of primary rays
 constexpr int kTilePixels = 64;
-constexpr int kStackMax = 32;         // per-lane traversal stack entries (tree depth limit)
+constexpr int kStackMax = 48;         // per-lane traversal stack entries (tree depth limit)
 constexpr int kAccumChannels = 3;     // r, g, b planes of 64 words per tile
 constexpr double kAccumScale = 68719476736.0;  // 2^36 fixed-point units per 1.0
 constexpr int kMatShift = 28;         // Prim::id = object id | material type << 28 | kind << 30

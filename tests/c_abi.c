@@ -69,6 +69,11 @@ int main(int argc, char** argv) {
 	OK(rthip_render_accumulate(ctx, &p));
 	rthip_stats st;
 	OK(rthip_get_stats(ctx, &st));
+	{
+		int64_t bad = -1; int32_t dev_nodes = 0, dev_depth = 0;
+		OK(rthip_scene_validate(ctx, &bad, &dev_nodes, &dev_depth));
+		EXPECT(bad == 0 && dev_nodes == st.n_nodes && dev_depth == st.tree_depth);
+	}
 	EXPECT(st.paths == 64u * 40u * 3u && st.rays >= st.paths);
 	void* dptr = NULL;
 	uint64_t words = 0;
