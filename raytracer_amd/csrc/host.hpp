@@ -49,7 +49,7 @@ struct FlatScene {
 	// (build_gpu.hpp), which also fills in depth, start and the quantised nodes.
 	struct GpuPlan {
 		bool on = false;
-		int32_t first = 0, count = 0, leaf_size = 4, n_leaves = 0, node_base = 0;
+		int32_t first = 0, count = 0, leaf_size = 1, n_leaves = 0, node_base = 0;
 		double clo[3] = {0, 0, 0}, cinv[3] = {0, 0, 0};  // box of the primitive centres: low corner, 1 / extent
 		bool quantise = false;
 	} gpu;
@@ -60,7 +60,7 @@ struct FlatScene {
 struct BuildOptions {
 	bool tree_ref = false;     // RTHIP_TREE=ref: the device tree keeps the reference's shape (default: surface-area build)
 	bool tree_gpu = false;     // RTHIP_TREE=gpu: the device tree is a linear BVH built on the GPU (scenes of at least two leaves; contexts only)
-	int gpu_leaf = 4;          // RTHIP_GPU_LEAF: primitives per leaf of that build, 1..7
+	int gpu_leaf = 1;          // RTHIP_GPU_LEAF: primitives per leaf of that build, 1..7 (1 traces fastest: 1.4 against 0.5 Gpaths/s with 4 on a million objects)
 	int sah_leaf = 4;          // RTHIP_SAH_LEAF: largest leaf of the surface-area build, 1..7
 	double sah_cprim = -1.0;   // RTHIP_SAH_CPRIM: cost of a primitive test against a node visit; < 0 = chosen per scene
 	int sah_sweep = -1;        // RTHIP_SAH_SWEEP: exact sweep up to this many primitives per range; < 0 = chosen per scene

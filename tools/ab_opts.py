@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 CAM5 = ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0)
+# any other name is taken as a scene of rt.Scene.generate (e.g. synthetic:1500) under the cfg5 camera
 WL = {"cfg2": ("default", 10, CAM, 32), "cfg3": ("sample", 50, CAM, 32), "cfg5": ("synthetic:1000000", 50, CAM5, 8)}
 args = sys.argv[1:]
 which = ["cfg2", "cfg3"]
@@ -16,7 +17,7 @@ if args and args[0] == "--spp":
     spp_override, args = int(args[1]), args[2:]
 sets = args or ["-"]
 for name in which:
-    scene, depth, cam, spp = WL[name]
+    scene, depth, cam, spp = WL.get(name, (name, 50, CAM5, 8))
     spp = spp_override or spp
     sc = rt.Scene.generate(scene)
     for spec in sets:
