@@ -7,8 +7,8 @@ import raytracer_amd as rt
 CAM5 = ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0)
 for n in [int(a) for a in sys.argv[1:]] or [1000000]:
     sc = rt.Scene.generate(f"synthetic:{n}", 0x5EED0001)
-    for name, opts in [("host surface-area build", {}), ("device build, 4 per leaf", {"tree_gpu": 1}), ("device build, 2 per leaf", {"tree_gpu": 1, "gpu_leaf": 2}),
-                       ("device build, 1 per leaf", {"tree_gpu": 1, "gpu_leaf": 1})]:
+    for name, opts in [("host surface-area build", {}), ("device build, 1 per leaf", {"tree_gpu": 1}), ("device build, 2 per leaf", {"tree_gpu": 1, "gpu_leaf": 2}),
+                       ("device build, 4 per leaf", {"tree_gpu": 1, "gpu_leaf": 4})]:
         r = rt.Renderer(sc, rt.Camera(*CAM5, 1920, 1080), max_depth=50, seed=1, options=opts)
         t = []
         for _ in range(3):
