@@ -17,15 +17,23 @@ for which, scene, depth in (("cfg2", "default", 10), ("cfg3", "sample", 50)):
         s = r.stats(); best = max(best, s["paths"] / s["kernel_ms"] / 1e3)
     out[which] = best
     r.close()
+for name, w, h in (("frame1080_us", 1920, 1080), ("frame270_us", 480, 270)):   # the 1-spp frame, kernel time in microseconds
+    r = rt.Renderer(rt.Scene.generate("default"), rt.Camera(*CAM, w, h), max_depth=10, seed=1)
+    for _ in range(3): r.accumulate(1)
+    ks = []
+    for _ in range(12):
+        r.accumulate(1); ks.append(r.stats()["kernel_ms"])
+    out[name] = min(ks) * 1e3
+    r.close()
 print(json.dumps(out))
 ''' % ROOT
 res = {l: [] for l in libs}
 for rnd in range(2):
     for l in libs:
         env = dict(os.environ, RTHIP_LIBRARY=os.path.join(ROOT, "raytracer_amd", l))
-        o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=200)
         if o.returncode != 0:
             print(l, "FAILED", o.stderr[-400:]); continue
         res[l].append(json.loads(o.stdout.strip().splitlines()[-1]))
 for l in libs:
-    print(l, " ".join(f"{k}: " + "/".join(f"{r[k]:.0f}" for r in res[l]) for k in ("cfg2", "cfg3")))
+    print(l, " ".join(f"{k}: " + "/".join(f"{r[k]:.0f}" for r in res[l]) for k in ("cfg2", "cfg3", "frame1080_us", "frame270_us")))
