@@ -86,3 +86,50 @@ def test_gpu_build_is_repeatable_and_rebuilds(rt):
     # f32 paths may differ between two trees only where a hit lies within rounding of a box face: nearly all words agree
     assert (host_words != first).mean() < 1e-3
     r.close()
+
+
+def _objects(rt, centres, radius, kinds=None):
+    from raytracer_amd import _native as N
+    n = len(centres)
+    o = np.zeros(n, dtype=N.OBJECT_DTYPE)
+    o["kind"] = N.SPHERE if kinds is None else kinds
+    o["material"] = N.LAMBERTIAN
+    o["center"] = centres
+    o["extent"][:, 0] = radius
+    o["extent"][:, 1] = radius
+    o["extent"][:, 2] = radius
+    o["albedo"] = 0.5
+    return rt.Scene(o)
+
+
+@pytest.mark.parametrize("case", ["same_centre", "on_a_line", "two_clusters", "hollow_shells"])
+def test_gpu_build_degenerate_layouts(rt, oracle, case):
+    """Layouts that give a Morton-code builder nothing to split on (equal codes fall back on the
+    primitive's index), or everything on one axis, or two far clusters; and many gated spheres."""
+    from raytracer_amd import _native as N
+    g = np.random.default_rng(3)
+    n = 700
+    if case == "same_centre":       # concentric spheres of growing radius, seen from outside and (via glass) inside
+        sc = _objects(rt, np.tile([0.0, 1.0, 0.0], (n, 1)), np.linspace(0.05, 3.0, n))
+        sc.objects["material"][::3] = N.DIELECTRIC
+        sc.objects["param"][::3] = 1.5
+    elif case == "on_a_line":
+        c = np.zeros((n, 3)); c[:, 0] = np.linspace(-40, 40, n); c[:, 1] = 1.0
+        sc = _objects(rt, c, g.uniform(0.05, 0.3, n), kinds=np.where(np.arange(n) % 2 == 0, N.SPHERE, N.CUBE))
+    elif case == "two_clusters":
+        c = np.concatenate([g.normal(0, 0.5, (n // 2, 3)) + [-2000, 1, 0], g.normal(0, 0.5, (n - n // 2, 3)) + [3, 1, 0]])
+        sc = _objects(rt, c, g.uniform(0.02, 0.1, n))
+    else:
+        from test_gpu_configs import hollow_shells
+        sc = hollow_shells(rt, 4000)
+    cam = ((13.0, 4.0, 9.0), (-13.0, -3.0, -9.0), 25.0, 10.0, 0.1, 160, 90)
+    r = rt.Renderer(sc, rt.Camera(*cam), seed=21, precision=rt.F64, max_depth=8, options={"tree_gpu": 1})
+    r.validate_tree()
+    osc = oracle.OracleScene(sc.objects)
+    desc = oracle.camera_desc(*cam)
+    ref = osc.trace_primary(desc, oracle.TIGHT, jitter=True, seed=21, sample=0)
+    for a, b in zip(ref, r.trace_primary(rt.F64, jitter=True, sample=0)):
+        assert np.array_equal(a, b)
+    _, smp, cnt, _ = osc.render(desc, 2, 8, 21, oracle.TIGHT, samples=True)
+    assert np.array_equal(r.render_samples(2), smp) and r.stats()["rays"] == cnt["rays"]
+    r.close()
