@@ -99,7 +99,9 @@ int32_t rthip_create(int32_t device, rthip_ctx** out);
 void rthip_destroy(rthip_ctx* ctx);
 /* Message for the last non-OK status of this context (or of rthip_create when ctx is NULL). */
 const char* rthip_last_error(const rthip_ctx* ctx);
-/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream, which is
+ * NOT ordered against the default stream: to launch on the default stream itself (handle 0 in
+ * torch) pass hipStreamLegacy.  Waits for what is queued on the stream it leaves. */
 int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
 
 /* Tuning and build knobs (no counterpart in the reference, which has no configuration at all).
