@@ -883,6 +883,15 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 		unsigned long long t_ph = phase_begin<kCount>();
 		if (state == kShade) {
 			region_tick<kCount>(rg, kRegShade);
+			if constexpr (kCount && kTally) {  // which arm of the shading code each lane takes: the arms run one after the other
+				if (tv.best_prim < 0) region_tick<kCount>(rg, kRegSky);
+				else {
+					const int m = (prims[tv.best_prim].id >> kMatShift) & 3;
+					if (m == RTHIP_DIELECTRIC) region_tick<kCount>(rg, kRegGlass);
+					else if (m == RTHIP_METAL) region_tick<kCount>(rg, kRegMetal);
+					else region_tick<kCount>(rg, kRegLambert);
+				}
+			}
 			n_rays++;
 			RayT<Real> next;
 			if (shade_ray<Real>(ray, tv.best_t, tv.best_prim, prims, mats, A.sky_mode, rng, T, L, depth, &next)) {
