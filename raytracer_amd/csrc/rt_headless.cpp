@@ -72,7 +72,9 @@ int usage() {
 	std::fprintf(stderr,
 	             "usage: rt_headless --backend hip [--scene default|sample|simple|glass|metal|wallpaper|synthetic:N]\n"
 	             "       [--width W] [--height H] [--spp N] [--max-depth D] [--seed S] [--scene-seed S] [--precision f32|f64]\n"
-	             "       [--sky reference|wallpaper] [--device I] [--chunk-spp N] [--out output.png]\n");
+	             "       [--sky reference|wallpaper] [--device I] [--chunk-spp N] [--out output.png]\n"
+	             "       [--gpus N] [--split spp|tile] [--devices I,J,...]   several GPUs from this one process: every GPU renders its\n"
+	             "       share (its slice of the samples, or its 8x8 tiles), the shares are summed on the first GPU\n");
 	return 2;
 }
 
@@ -82,7 +84,8 @@ int main(int argc, char** argv) {
 	// raytracer_headless/src/main.rs:15-18
 	int width = 2560, height = 1440, max_depth = 10, device = 0;
 	uint32_t samples = 800, seed = 0x5EED0001u, scene_seed = 0x5EED0001u, chunk_spp = 100;
-	std::string backend = "hip", scene = "default", out = "output.png", precision = "f32", sky = "reference";
+	std::string backend = "hip", scene = "default", out = "output.png", precision = "f32", sky = "reference", split = "spp", device_list;
+	int gpus = 1;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -100,13 +103,29 @@ int main(int argc, char** argv) {
 		else if (a == "--device" && (v = next())) device = std::atoi(v);
 		else if (a == "--chunk-spp" && (v = next())) chunk_spp = (uint32_t)std::strtoul(v, nullptr, 0);
 		else if (a == "--out" && (v = next())) out = v;
+		else if (a == "--gpus" && (v = next())) gpus = std::atoi(v);
+		else if (a == "--split" && (v = next())) split = v;
+		else if (a == "--devices" && (v = next())) device_list = v;
 		else return usage();
 	}
 	if (backend != "hip") {
 		std::fprintf(stderr, "rt_headless: only --backend hip is built here; the CPU backend is the reference's own raytracer_headless\n");
 		return 2;
 	}
-	if (samples == 0 || width < 1 || height < 1 || chunk_spp == 0) return usage();
+	if (samples == 0 || width < 1 || height < 1 || chunk_spp == 0 || gpus < 1 || gpus > 64 || (split != "spp" && split != "tile")) return usage();
+	// the GPU of every share: --devices as given (an ordinal may repeat: shares then take turns on that GPU), else device, device + 1, ...
+	std::vector<int> devices;
+	for (size_t pos = 0; pos < device_list.size();) {
+		size_t comma = device_list.find(',', pos);
+		if (comma == std::string::npos) comma = device_list.size();
+		devices.push_back(std::atoi(device_list.substr(pos, comma - pos).c_str()));
+		pos = comma + 1;
+	}
+	if (devices.empty()) for (int k = 0; k < gpus; k++) devices.push_back(device + k);
+	if ((int)devices.size() != gpus) {
+		if (!device_list.empty() && gpus == 1) gpus = (int)devices.size();
+		else return usage();
+	}
 
 	int64_t n = 0;
 	if (rthip_scene_generate(scene.c_str(), scene_seed, nullptr, 0, &n) != RTHIP_OK) {
@@ -116,14 +135,10 @@ int main(int argc, char** argv) {
 	std::vector<rthip_object> objects((size_t)n);
 	rthip_scene_generate(scene.c_str(), scene_seed, objects.data(), n, &n);
 
-	rthip_ctx* ctx = nullptr;
-	if (rthip_create(device, &ctx) != RTHIP_OK) {
-		std::fprintf(stderr, "rt_headless: %s\n", rthip_last_error(nullptr));
-		return 1;
-	}
-	auto die = [&](const char* what) {
-		std::fprintf(stderr, "rt_headless: %s: %s\n", what, rthip_last_error(ctx));
-		rthip_destroy(ctx);
+	std::vector<rthip_ctx*> ctxs((size_t)gpus, nullptr);
+	auto die = [&](const char* what, rthip_ctx* of = nullptr) {
+		std::fprintf(stderr, "rt_headless: %s: %s\n", what, rthip_last_error(of));
+		for (rthip_ctx* c : ctxs) if (c) rthip_destroy(c);
 		return 1;
 	};
 	// raytracer_headless/src/main.rs:20-30
@@ -139,8 +154,12 @@ int main(int argc, char** argv) {
 		cam.fov = 20.0;
 	}
 	cam.focus_dist = 10.0; cam.defocus_angle = 0.6; cam.width = width; cam.height = height;
-	if (rthip_scene_upload(ctx, objects.data(), n) != RTHIP_OK) return die("scene");
-	if (rthip_camera_set(ctx, &cam) != RTHIP_OK) return die("camera");
+	for (int k = 0; k < gpus; k++) {  // the scene is replicated: every GPU holds its own copy of the tree
+		if (rthip_create(devices[(size_t)k], &ctxs[(size_t)k]) != RTHIP_OK) return die("context");
+		if (rthip_scene_upload(ctxs[(size_t)k], objects.data(), n) != RTHIP_OK) return die("scene", ctxs[(size_t)k]);
+		if (rthip_camera_set(ctxs[(size_t)k], &cam) != RTHIP_OK) return die("camera", ctxs[(size_t)k]);
+	}
+	rthip_ctx* ctx = ctxs[0];
 
 	auto start = std::chrono::steady_clock::now();  // main.rs:32
 	rthip_render_params p;
@@ -151,13 +170,31 @@ int main(int argc, char** argv) {
 	uint64_t rays = 0;
 	double kernel_ms = 0;
 	for (uint32_t done = 0; done < samples; done += chunk_spp) {  // main.rs:43: the sample loop, in launches of chunk_spp
-		p.spp_begin = done;
-		p.spp_count = std::min(chunk_spp, samples - done);
-		if (rthip_render_accumulate(ctx, &p) != RTHIP_OK) return die("render");
-		rthip_stats s;
-		rthip_get_stats(ctx, &s);
-		rays += s.rays; kernel_ms += s.kernel_ms;
+		const uint32_t count = std::min(chunk_spp, samples - done);
+		// every GPU its share of this launch, queued without waiting; then all of them are waited for
+		std::vector<char> launched((size_t)gpus, 0);
+		for (int k = 0; k < gpus; k++) {
+			if (split == "tile") { p.part_index = k; p.part_count = gpus; p.spp_begin = done; p.spp_count = count; }
+			else {
+				const uint32_t lo = (uint32_t)((uint64_t)count * (uint64_t)k / (uint64_t)gpus), hi = (uint32_t)((uint64_t)count * (uint64_t)(k + 1) / (uint64_t)gpus);
+				p.part_index = 0; p.part_count = 1; p.spp_begin = done + lo; p.spp_count = hi - lo;
+			}
+			if (p.spp_count == 0) continue;
+			if (rthip_render_accumulate_async(ctxs[(size_t)k], &p) != RTHIP_OK) return die("render", ctxs[(size_t)k]);
+			launched[(size_t)k] = 1;
+		}
+		double slowest = 0;
+		for (int k = 0; k < gpus; k++) {
+			if (!launched[(size_t)k]) continue;
+			if (rthip_synchronize(ctxs[(size_t)k]) != RTHIP_OK) return die("render", ctxs[(size_t)k]);
+			rthip_stats s;
+			rthip_get_stats(ctxs[(size_t)k], &s);
+			rays += s.rays; slowest = std::max(slowest, s.kernel_ms);
+		}
+		kernel_ms += slowest;
 	}
+	// the shares are sums of integers: added on the first GPU they give the words one GPU would have produced
+	if (gpus > 1 && rthip_merge_local(ctxs.data(), gpus, 0) != RTHIP_OK) return die("merge", ctx);
 	double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
 	std::printf("Rendering took %gs\n", secs);  // main.rs:59-62
 	double paths = (double)width * height * samples;
@@ -165,8 +202,8 @@ int main(int argc, char** argv) {
 	            kernel_ms / 1e3, (long long)n);
 
 	std::vector<uint8_t> rgb((size_t)width * height * 3);
-	if (rthip_read_rgb8(ctx, samples, rgb.data()) != RTHIP_OK) return die("readback");  // main.rs:55,64-69
-	rthip_destroy(ctx);
+	if (rthip_read_rgb8(ctx, samples, rgb.data()) != RTHIP_OK) return die("readback", ctx);  // main.rs:55,64-69
+	for (rthip_ctx* c : ctxs) rthip_destroy(c);
 	if (!write_png(out, rgb.data(), width, height)) {  // main.rs:70-72
 		std::fprintf(stderr, "failed to save to %s\n", out.c_str());
 		return 1;

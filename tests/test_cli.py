@@ -107,3 +107,22 @@ def test_cfg1_headless_default_render(rt, oracle, tmp_path):
     assert abs(a.mean() - b.mean()) <= 5e-3 * b.mean(), (a.mean(), b.mean())
     print(f"[cfg1] 2560x1440: first two samples RMSE {rmse:.2e} against the CPU reference algorithm ({cnt['rays']} rays); "
           f"800-spp image mean {a.mean():.4f} against {b.mean():.4f}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", ["spp", "tile"])
+@pytest.mark.parametrize("shares", [2, 3])
+def test_cli_several_gpus_from_one_process(tmp_path, split, shares):
+    """rt_headless --gpus N: N contexts in one process (here all on GPU 0, taking turns), every one
+    renders its share, rthip_merge_local sums them on the first: the PNG equals the one-GPU PNG
+    byte for byte, for both ways of sharing and a sample count the shares do not divide."""
+    w, h, spp = 200, 120, 7
+    common = ["--backend", "hip", "--scene", "sample", "--width", str(w), "--height", str(h), "--spp", str(spp), "--seed", "5", "--chunk-spp", "5"]
+    one, many = str(tmp_path / "one.png"), str(tmp_path / "many.png")
+    a = subprocess.run([EXE] + common + ["--out", one], capture_output=True, text=True, timeout=120)
+    b = subprocess.run([EXE] + common + ["--gpus", str(shares), "--devices", ",".join(["0"] * shares), "--split", split, "--out", many],
+                       capture_output=True, text=True, timeout=120)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert np.array_equal(read_png_rgb8(one), read_png_rgb8(many))
+    bad = subprocess.run([EXE] + common + ["--gpus", "2", "--devices", "0", "--out", many], capture_output=True, text=True)
+    assert bad.returncode != 0 and "usage" in bad.stderr
