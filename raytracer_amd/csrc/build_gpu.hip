@@ -5,9 +5,8 @@
 // reference's own tree decides, see host.cpp), so the tree the kernels walk may come from any
 // builder.  This one is a linear BVH: Morton codes of the primitive centres, one radix sort,
 // leaves of `leaf_size` consecutive primitives, the hierarchy over the leaves' codes found by
-// every inner node on its own (Karras 2012), and a bottom-up pass that unions boxes, the second
-// child to arrive carrying on.  It is for scenes that change from frame to frame: a million
-// primitives take a few milliseconds, where the host's surface-area build takes a quarter of a
+// every inner node on its own (Karras 2012), and the boxes bottom up, one launch per level.  It is for scenes that change from frame to frame: a million
+// primitives take 1.3 ms of kernels, where the host's surface-area build takes a quarter of a
 // second; the tree is coarser and traces slower than that one.
 //
 // Input, already in the scene blobs (both precisions): the primitives [first, first + count) in
@@ -126,7 +125,8 @@ __device__ __forceinline__ int prefix(const unsigned long long* keys, int n, int
 
 // One thread per inner node: its range of leaves and where that range splits (Karras 2012).
 // parent_*: index of the parent inner node, bit 31 set for "I am its right child"; the root has -1.
-__global__ void hierarchy_kernel(GpuBuildIO io, const unsigned long long* keys, const int32_t* leaf_codes, int32_t* parent_inner, int32_t* parent_leaf) {
+// child_ref[2 i + side]: the child as the fitting pass wants it, a leaf index or ~(inner node index).
+__global__ void hierarchy_kernel(GpuBuildIO io, const unsigned long long* keys, const int32_t* leaf_codes, int32_t* parent_inner, int32_t* parent_leaf, int32_t* child_ref) {
 	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
 	const int n = io.n_leaves;
 	if (i >= n - 1) return;
@@ -149,10 +149,10 @@ __global__ void hierarchy_kernel(GpuBuildIO io, const unsigned long long* keys, 
 	Node<float>* n32 = reinterpret_cast<Node<float>*>(io.blob32);
 	Node<double>* n64 = reinterpret_cast<Node<double>*>(io.blob64);
 	int32_t child[2];
-	if (lo == gamma) { child[0] = leaf_codes[gamma]; parent_leaf[gamma] = i; }
-	else { child[0] = io.node_base + gamma; parent_inner[gamma] = i; }
-	if (hi == gamma + 1) { child[1] = leaf_codes[gamma + 1]; parent_leaf[gamma + 1] = i | (int32_t)0x80000000; }
-	else { child[1] = io.node_base + gamma + 1; parent_inner[gamma + 1] = i | (int32_t)0x80000000; }
+	if (lo == gamma) { child[0] = leaf_codes[gamma]; parent_leaf[gamma] = i; child_ref[2 * i] = gamma; }
+	else { child[0] = io.node_base + gamma; parent_inner[gamma] = i; child_ref[2 * i] = ~gamma; }
+	if (hi == gamma + 1) { child[1] = leaf_codes[gamma + 1]; parent_leaf[gamma + 1] = i | (int32_t)0x80000000; child_ref[2 * i + 1] = gamma + 1; }
+	else { child[1] = io.node_base + gamma + 1; parent_inner[gamma + 1] = i | (int32_t)0x80000000; child_ref[2 * i + 1] = ~(gamma + 1); }
 	for (int c = 0; c < 2; c++) { n32[io.node_base + i].child[c] = child[c]; n64[io.node_base + i].child[c] = child[c]; }
 	if (i == 0) parent_inner[0] = -1;
 }
@@ -181,53 +181,41 @@ __device__ __forceinline__ void store_child_box(Node<float>* n32, Node<double>* 
 		}
 	}
 }
-__device__ __forceinline__ double load_coherent(const double* p) {  // written by another workgroup: read at the L2
-	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Boxes, bottom up, one launch per level of the hierarchy (deepest first): a launch boundary is all the
+// ordering the pass needs.  (One kernel in which the second child to arrive at a node carries on
+// upwards needs a fence and reads past the caches at every step, and took 10.7 ms for a million
+// leaves where these launches take under one.)
+// depth_kernel: inner nodes above each inner node; the deepest count + 1 is the stack a ray can need.
+__global__ void depth_kernel(GpuBuildIO io, const int32_t* parent_inner, int32_t* depth_inner, int32_t* deepest) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	if (i >= io.n_leaves - 1) return;
+	int d = 0;
+	for (int32_t p = parent_inner[i]; p != -1; p = parent_inner[p & 0x7fffffff]) d++;
+	depth_inner[i] = d;
+	atomicMax(deepest, d + 1);
 }
-
-// One thread per leaf climbs towards the root; at every inner node the first child to arrive
-// stops, the second unions both boxes and goes on.  side_b32[2 * node + side] keeps the f32-side
-// bounds as planes (the node itself holds them as centre and half extent, which cannot be
-// unioned exactly).  Also counts the inner nodes above each leaf: the deepest count is the
-// traversal stack a ray can need.
-__global__ void fit_kernel(GpuBuildIO io, const int32_t* parent_inner, const int32_t* parent_leaf, const Box6* leaf_b64, const Box6* leaf_b32,
-                           Box6* side_b32, uint32_t* arrived, int32_t* deepest) {
-	const uint32_t leaf = blockIdx.x * kBlock + threadIdx.x;
-	if (leaf >= (uint32_t)io.n_leaves) return;
+// fit_level_kernel: every inner node of depth `level` takes its children's boxes (a leaf's own, or the
+// one an inner child computed in the launch before), writes them into its node and keeps their union.
+__global__ void fit_level_kernel(GpuBuildIO io, int level, const int32_t* depth_inner, const int32_t* child_ref, const Box6* leaf_b64, const Box6* leaf_b32,
+                                 Box6* node_b64, Box6* node_b32) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	if (i >= io.n_leaves - 1 || depth_inner[i] != level) return;
 	Node<float>* n32 = reinterpret_cast<Node<float>*>(io.blob32);
 	Node<double>* n64 = reinterpret_cast<Node<double>*>(io.blob64);
-	{
-		int levels = 0;
-		for (int32_t p = parent_leaf[leaf]; p != -1; p = parent_inner[p & 0x7fffffff]) levels++;
-		atomicMax(deepest, levels);
+	Box6 u64, u32;
+	for (int side = 0; side < 2; side++) {
+		const int32_t ref = child_ref[2 * i + side];
+		const Box6 b64 = ref >= 0 ? leaf_b64[ref] : node_b64[~ref];
+		const Box6 b32 = ref >= 0 ? leaf_b32[ref] : node_b32[~ref];
+		store_child_box(&n32[io.node_base + i], &n64[io.node_base + i], side, b64, b32);
+		if (side == 0) { u64 = b64; u32 = b32; } else { box_join(&u64, b64); box_join(&u32, b32); }
 	}
-	Box6 b64 = leaf_b64[leaf], b32 = leaf_b32[leaf];
-	int32_t p = parent_leaf[leaf];
-	for (;;) {
-		const int node = p & 0x7fffffff, side = (p >> 31) & 1;
-		store_child_box(&n32[io.node_base + node], &n64[io.node_base + node], side, b64, b32);
-		side_b32[2 * node + side] = b32;
-		__threadfence();
-		if (atomicAdd(&arrived[node], 1u) == 0u) return;  // the sibling is still on its way: it will carry on
-		__threadfence();
-		const Node<double>* me64 = &n64[io.node_base + node];
-		const Box6* other32 = &side_b32[2 * node + (1 - side)];
-		for (int k = 0; k < 3; k++) {
-			b64.lo[k] = fmin(b64.lo[k], load_coherent(&me64->box[6 * (1 - side) + kLoSlot[k]]));
-			b64.hi[k] = fmax(b64.hi[k], load_coherent(&me64->box[6 * (1 - side) + kHiSlot[k]]));
-			b32.lo[k] = fmin(b32.lo[k], load_coherent(&other32->lo[k]));
-			b32.hi[k] = fmax(b32.hi[k], load_coherent(&other32->hi[k]));
-		}
-		p = parent_inner[node];
-		if (p == -1) {
-			// the root of the hierarchy: with a leaf of oversized primitives beside it, node 0 holds
-			// that leaf on the left and this tree on the right
-			if (io.node_base == 1) {
-				store_child_box(&n32[0], &n64[0], 1, b64, b32);
-				n32[0].child[1] = n64[0].child[1] = io.node_base;
-			}
-			return;
-		}
+	node_b64[i] = u64; node_b32[i] = u32;
+	if (i == 0 && io.node_base == 1) {
+		// the root of the hierarchy: with a leaf of oversized primitives beside it, node 0 holds
+		// that leaf on the left and this tree on the right
+		store_child_box(&n32[0], &n64[0], 1, u64, u32);
+		n32[0].child[1] = n64[0].child[1] = io.node_base;
 	}
 }
 
@@ -280,17 +268,17 @@ hipError_t gpu_build_tree(const GpuBuildIO& io_in, hipStream_t stream, GpuBuildR
 	Scratch mem;
 	const size_t n = (size_t)io.count, nl = (size_t)io.n_leaves;
 	unsigned long long *keys_a, *keys_b, *leaf_keys;
-	uint32_t *vals_a, *vals_b, *arrived;
+	uint32_t *vals_a, *vals_b;
 	Prim<float>* in_p32; Prim<double>* in_p64; Mat<float>* in_m32; Mat<double>* in_m64;
-	int32_t *leaf_codes, *parent_inner, *parent_leaf, *deepest;
-	Box6 *leaf_b64, *leaf_b32, *side_b32;
+	int32_t *leaf_codes, *parent_inner, *parent_leaf, *deepest, *child_ref, *depth_inner;
+	Box6 *leaf_b64, *leaf_b32, *node_b64, *node_b32;
 	int* overflow;
 	GB_TRY(mem.get(&keys_a, n)); GB_TRY(mem.get(&keys_b, n)); GB_TRY(mem.get(&vals_a, n)); GB_TRY(mem.get(&vals_b, n));
 	GB_TRY(mem.get(&in_p32, n)); GB_TRY(mem.get(&in_p64, n)); GB_TRY(mem.get(&in_m32, n)); GB_TRY(mem.get(&in_m64, n));
 	GB_TRY(mem.get(&leaf_codes, nl)); GB_TRY(mem.get(&leaf_keys, nl)); GB_TRY(mem.get(&leaf_b64, nl)); GB_TRY(mem.get(&leaf_b32, nl));
-	GB_TRY(mem.get(&parent_inner, nl)); GB_TRY(mem.get(&parent_leaf, nl)); GB_TRY(mem.get(&side_b32, 2 * nl)); GB_TRY(mem.get(&arrived, nl));
+	GB_TRY(mem.get(&parent_inner, nl)); GB_TRY(mem.get(&parent_leaf, nl)); GB_TRY(mem.get(&node_b64, nl)); GB_TRY(mem.get(&node_b32, nl));
+	GB_TRY(mem.get(&child_ref, 2 * nl)); GB_TRY(mem.get(&depth_inner, nl));
 	GB_TRY(mem.get(&deepest, 1)); GB_TRY(mem.get(&overflow, 1));
-	GB_TRY(hipMemsetAsync(arrived, 0, nl * sizeof(uint32_t), stream));
 	GB_TRY(hipMemsetAsync(deepest, 0, sizeof(int32_t), stream));
 	GB_TRY(hipMemsetAsync(overflow, 0, sizeof(int), stream));
 	// the unsorted primitives and materials, aside: the scene blobs receive them in leaf order
@@ -308,17 +296,23 @@ hipError_t gpu_build_tree(const GpuBuildIO& io_in, hipStream_t stream, GpuBuildR
 	GB_TRY(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, stream));
 	hipLaunchKernelGGL(leaves_kernel, dim3(grid_l), dim3(kBlock), 0, stream, io, keys_b, vals_b, in_p32, in_p64, in_m32, in_m64, leaf_codes, leaf_keys, leaf_b64, leaf_b32);
 	GB_TRY(hipGetLastError());
-	hipLaunchKernelGGL(hierarchy_kernel, dim3(grid_l), dim3(kBlock), 0, stream, io, leaf_keys, leaf_codes, parent_inner, parent_leaf);
+	hipLaunchKernelGGL(hierarchy_kernel, dim3(grid_l), dim3(kBlock), 0, stream, io, leaf_keys, leaf_codes, parent_inner, parent_leaf, child_ref);
 	GB_TRY(hipGetLastError());
-	hipLaunchKernelGGL(fit_kernel, dim3(grid_l), dim3(kBlock), 0, stream, io, parent_inner, parent_leaf, leaf_b64, leaf_b32, side_b32, arrived, deepest);
+	hipLaunchKernelGGL(depth_kernel, dim3(grid_l), dim3(kBlock), 0, stream, io, parent_inner, depth_inner, deepest);
 	GB_TRY(hipGetLastError());
 	int32_t levels = 0;
-	Node<float> node0;
 	GB_TRY(hipMemcpyAsync(&levels, deepest, sizeof(levels), hipMemcpyDeviceToHost, stream));
-	GB_TRY(hipMemcpyAsync(&node0, io.blob32, sizeof(node0), hipMemcpyDeviceToHost, stream));
 	GB_TRY(hipStreamSynchronize(stream));
 	res->levels = levels;
 	res->quantised = false;
+	if (levels > kStackMax) return hipSuccess;  // deeper than a traversal stack: the caller turns the scene down
+	for (int level = levels - 1; level >= 0; level--) {
+		hipLaunchKernelGGL(fit_level_kernel, dim3(grid_l), dim3(kBlock), 0, stream, io, level, depth_inner, child_ref, leaf_b64, leaf_b32, node_b64, node_b32);
+		GB_TRY(hipGetLastError());
+	}
+	Node<float> node0;
+	GB_TRY(hipMemcpyAsync(&node0, io.blob32, sizeof(node0), hipMemcpyDeviceToHost, stream));
+	GB_TRY(hipStreamSynchronize(stream));
 	if (io.quantise) {
 		// the grid spans the tree's own bounds (the leaf of oversized primitives stays outside it)
 		QFrame& f = res->frame;
