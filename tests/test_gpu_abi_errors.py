@@ -90,3 +90,36 @@ def test_misuse_returns_status_codes(rt):
     N.check(lib.rthip_get_stats(ctx, C.byref(st)), ctx)
     assert st.paths == 64 * 36
     lib.rthip_destroy(ctx)
+
+
+def test_contexts_on_several_host_threads(rt):
+    """A context belongs to one thread at a time, but contexts are independent: four host threads
+    with a context each (different scenes, the ctypes calls run without the interpreter lock)
+    produce the words a lone context produces."""
+    import threading
+    cam = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6, 160, 90)
+    scenes = ["default", "sample", "glass", "synthetic:3000"]
+
+    def words(name, out, k, rounds):
+        r = rt.Renderer(rt.Scene.generate(name), rt.Camera(*cam), seed=4, max_depth=8)
+        for _ in range(rounds):
+            r.reset_accumulation()
+            r.accumulate(3, spp_begin=0)
+            r.accumulate(2, spp_begin=3, noalloc=(k % 2 == 0 and rounds == 1))   # the static scratch is one per GPU: only unshared use
+        _, n = r.accum_buffer()
+        w = np.zeros(n, dtype=np.uint64)
+        r._check(r._lib.rthip_accum_download(r._ctx, w.ctypes.data, n))
+        out[k] = w
+        r.close()
+
+    alone = [None] * len(scenes)
+    for k, name in enumerate(scenes):
+        words(name, alone, k, 1)
+    together = [None] * len(scenes)
+    threads = [threading.Thread(target=words, args=(name, together, k, 5)) for k, name in enumerate(scenes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for a, b in zip(alone, together):
+        assert b is not None and np.array_equal(a, b)
