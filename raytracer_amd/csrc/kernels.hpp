@@ -508,9 +508,9 @@ __device__ __forceinline__ void trav_pop(Trav<Real>& tv, const int* stack) {
 template <typename Real, int kThreads, bool kCount>
 __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, int* stack, Tally& tally, Regions& rg,
                                            int32_t inner_exit = 0) {
-	const int32_t entered = (int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit;
+	const int32_t min_lanes = ((int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit + 15) >> 4;  // fewer than inner_exit sixteenths of those that entered
 	while (tv.cur >= 0) {
-		if ((int32_t)__popcll(__ballot(1)) * 16 < entered) break;  // the rest wait at leaves: serve them first
+		if ((int32_t)__popcll(__ballot(1)) < min_lanes) break;  // the rest wait at leaves: serve them first
 		region_tick<kCount>(rg, kRegInner);
 		const Node<Real>& n = nodes[tv.cur];
 		Real el, er;
@@ -537,9 +537,9 @@ __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& 
 template <int kThreads, bool kCount>
 __device__ __forceinline__ void trav_inner_q(Trav<float>& tv, const TravRay<float>& r, const QNode* nodes, int* stack, Tally& tally, Regions& rg,
                                              int32_t inner_exit) {
-	const int32_t entered = (int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit;
+	const int32_t min_lanes = ((int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit + 15) >> 4;
 	while (tv.cur >= 0) {
-		if ((int32_t)__popcll(__ballot(1)) * 16 < entered) break;
+		if ((int32_t)__popcll(__ballot(1)) < min_lanes) break;
 		region_tick<kCount>(rg, kRegInner);
 		const uint4* p = reinterpret_cast<const uint4*>(nodes + tv.cur);
 		const uint4 a = p[0], b = p[1];
