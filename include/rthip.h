@@ -110,7 +110,8 @@ int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
  * "scene_lds", "qnodes", "threads", "blocks_per_cu", "grid_reserve", "chunk", "trav_threshold", "inner_exit",
  * "regen_min", "block_order", "wf_batch", "count" take effect with the next render call; build
  * knobs "tree_ref" (1 = device tree in the reference's shape), "tree_gpu" (1 = device tree built
- * on the GPU, a linear BVH with "gpu_leaf" primitives per leaf), "sah_leaf", "sah_cprim",
+ * on the GPU, a linear BVH with "gpu_leaf" primitives per leaf), "sah_leaf", "sah_kind_cap" (at most so many
+ * spheres and so many cubes per leaf, 0 = no cap), "sah_cprim",
  * "sah_sweep", "big_leaf_min", "no_big_leaf", "no_qnodes", "build_threads", "tie_reverse"
  * (1 = equal sort keys of BVH::new in reversed order, see rthip_bvh_leaf_order) with the next
  * rthip_scene_upload.  Unknown names return RTHIP_ERR_INVALID. */

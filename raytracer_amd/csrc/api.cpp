@@ -629,6 +629,7 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		else if (k == "tree_gpu") b.tree_gpu = iv != 0;
 		else if (k == "gpu_leaf") b.gpu_leaf = iv;
 		else if (k == "sah_leaf") b.sah_leaf = iv;
+		else if (k == "sah_kind_cap") b.sah_kind_cap = iv;
 		else if (k == "sah_cprim") b.sah_cprim = value;
 		else if (k == "sah_sweep") b.sah_sweep = iv;
 		else if (k == "big_leaf_min") b.big_leaf_min = iv;

@@ -303,6 +303,7 @@ struct Builder {
 	FlatScene* out;
 	int max_depth = 0;
 	int max_leaf = 4;
+	int kind_cap = 0;  // surface-area build: at most this many spheres and this many cubes in a leaf, 0 = no cap
 	bool threads_on = true;  // large ranges are built on several threads (same result as on one)
 	bool tie_reverse = false;  // equal sort keys end up in reversed order (the other extreme of what sort_unstable_by may do)
 	int sweep_max = 48;  // exact sweep over sorted centroids up to this many primitives, 32 bins beyond
@@ -654,7 +655,14 @@ struct Builder {
 		while (((size_t)max_leaf << need) < n) need++;
 		bool force_median = need + 1 >= levels_left;
 		double parent_area = box_area(bounds);
-		double best_cost = (n <= (size_t)max_leaf) ? cost_prim * (double)n : INFINITY;
+		// a leaf may be capped per kind: the leaf loops of a wave run as long as its fullest leaf of each kind
+		bool may_be_leaf = n <= (size_t)max_leaf;
+		if (may_be_leaf && kind_cap > 0) {
+			int ns = 0, nc = 0;
+			for (size_t i = begin; i < end; i++) (objs[items[i].id].kind == RTHIP_SPHERE ? ns : nc)++;
+			may_be_leaf = ns <= kind_cap && nc <= kind_cap;
+		}
+		double best_cost = may_be_leaf ? cost_prim * (double)n : INFINITY;
 		int best_axis = -1;
 		double best_pos = 0;
 		size_t best_left = 0;
@@ -715,7 +723,7 @@ struct Builder {
 			if (mid == begin || mid == end) best_axis = -1;  // numerical corner: fall through to the median
 		}
 		if (best_axis < 0) {
-			if (n <= (size_t)max_leaf) return sah_leaf(begin, end);
+			if (may_be_leaf) return sah_leaf(begin, end);
 			// no useful SAH split (coincident centroids, a forced balanced split, or a leaf too large): median of the widest centroid axis
 			int axis = 0;
 			for (int k = 1; k < 3; k++)
@@ -760,6 +768,7 @@ BuildOptions BuildOptions::from_env() {
 	if (const char* v = std::getenv("RTHIP_TREE")) { o.tree_ref = std::string(v) == "ref"; o.tree_gpu = std::string(v) == "gpu"; }
 	if (const char* v = std::getenv("RTHIP_GPU_LEAF")) o.gpu_leaf = std::atoi(v);
 	if (const char* v = std::getenv("RTHIP_SAH_LEAF")) o.sah_leaf = std::atoi(v);
+	if (const char* v = std::getenv("RTHIP_SAH_KIND_CAP")) o.sah_kind_cap = std::atoi(v);
 	if (const char* v = std::getenv("RTHIP_SAH_CPRIM")) o.sah_cprim = std::atof(v);
 	if (const char* v = std::getenv("RTHIP_SAH_SWEEP")) o.sah_sweep = std::atoi(v);
 	if (const char* v = std::getenv("RTHIP_BIG_LEAF_MIN")) o.big_leaf_min = std::atoi(v);
@@ -831,6 +840,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	// 2. the device tree
 	bool use_sah = !opt.tree_ref;
 	b.max_leaf = std::max(1, std::min(7, opt.sah_leaf));
+	b.kind_cap = std::max(0, std::min(7, opt.sah_kind_cap));
 	if (opt.sah_cprim >= 0.0) b.cost_prim = opt.sah_cprim;
 	if (opt.sah_sweep >= 0) b.sweep_max = opt.sah_sweep;
 	bool big_ids_empty = true;

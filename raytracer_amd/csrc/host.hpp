@@ -62,6 +62,7 @@ struct BuildOptions {
 	bool tree_gpu = false;     // RTHIP_TREE=gpu: the device tree is a linear BVH built on the GPU (scenes of at least two leaves; contexts only)
 	int gpu_leaf = 1;          // RTHIP_GPU_LEAF: primitives per leaf of that build, 1..7 (1 traces fastest: 1.4 against 0.5 Gpaths/s with 4 on a million objects)
 	int sah_leaf = 4;          // RTHIP_SAH_LEAF: largest leaf of the surface-area build, 1..7
+	int sah_kind_cap = 0;      // RTHIP_SAH_KIND_CAP: at most this many spheres and this many cubes per leaf, 0 = no cap
 	double sah_cprim = -1.0;   // RTHIP_SAH_CPRIM: cost of a primitive test against a node visit; < 0 = chosen per scene
 	int sah_sweep = -1;        // RTHIP_SAH_SWEEP: exact sweep up to this many primitives per range; < 0 = chosen per scene
 	int big_leaf_min = 32;     // RTHIP_BIG_LEAF_MIN: scenes larger than this may get the leaf of oversized primitives
