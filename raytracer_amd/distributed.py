@@ -91,13 +91,24 @@ def init_abi_comm(renderer, rank, world, device):
     torch.distributed group that is already up.  Returns True when every rank succeeded; on False
     the caller merges through torch.distributed instead."""
     ok = 1
-    try:
-        raw = renderer.comm_unique_id() if rank == 0 else bytes(128)
-        ident = torch.tensor(list(raw), dtype=torch.uint8, device=device)
-        dist.broadcast(ident, src=0)
-        renderer.comm_init(bytes(ident.cpu().tolist()), rank, world)
-    except Exception as e:  # no librccl, or RCCL refused: every rank learns of it below
-        print(f"[distributed] rank {rank}: C-ABI communicator not available ({e})", flush=True)
+    raw = bytes(128)
+    if rank == 0:
+        try:
+            raw = renderer.comm_unique_id()
+        except Exception as e:  # no librccl: an all-zero id tells the others
+            print(f"[distributed] rank 0: C-ABI communicator not available ({e})", flush=True)
+            raw = bytes(128)
+    # every rank takes part in every collective below, whatever failed before it
+    ident = torch.tensor(list(raw), dtype=torch.uint8, device=device)
+    dist.broadcast(ident, src=0)
+    raw = bytes(ident.cpu().tolist())
+    if any(raw):
+        try:
+            renderer.comm_init(raw, rank, world)
+        except Exception as e:  # RCCL refused: every rank learns of it below
+            print(f"[distributed] rank {rank}: C-ABI communicator not available ({e})", flush=True)
+            ok = 0
+    else:
         ok = 0
     flag = torch.tensor([ok], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
