@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 sc = rt.Scene.generate("default")
-for w, h in ((1920, 1080), (960, 540), (480, 270), (3840, 2160)):
+SIZES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(1920, 1080), (960, 540), (480, 270), (3840, 2160)]
+for w, h in SIZES:
     for depth in (1, 2, 3, 5, 10):
         r = rt.Renderer(sc, rt.Camera(*CAM, w, h), max_depth=depth, seed=1)
         for _ in range(3):
