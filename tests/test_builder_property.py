@@ -16,8 +16,8 @@ COORDS = st.sampled_from([0.0, -0.0, 1e-9, 0.5, -3.0, 7.25, 1e4, -1e6])
 
 
 @st.composite
-def object_arrays(draw):
-    n = draw(st.integers(min_value=1, max_value=40))
+def object_arrays(draw, max_objects=40):
+    n = draw(st.integers(min_value=1, max_value=max_objects))
     o = np.zeros(n, dtype=N.OBJECT_DTYPE)
     for i in range(n):
         if i and draw(st.integers(0, 4)) == 0:

@@ -9,9 +9,7 @@ from test_builder_property import object_arrays
 pytestmark = pytest.mark.gpu
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
-@given(object_arrays())
-def test_degenerate_scenes_f64_bit_exact(rt, oracle, objs):
+def _check(rt, oracle, objs):
     cam = ((9.0, 4.0, 11.0), (-9.0, -3.5, -11.0), 40.0, 10.0, 0.2, 32, 24)
     osc = oracle.OracleScene(objs)
     desc = oracle.camera_desc(*cam)
@@ -27,3 +25,15 @@ def test_degenerate_scenes_f64_bit_exact(rt, oracle, objs):
         r.accumulate(2, spp_begin=0)
         assert r.stats()["paths"] == 32 * 24 * 2
         r.close()
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(object_arrays())
+def test_degenerate_scenes_f64_bit_exact(rt, oracle, objs):
+    _check(rt, oracle, objs)
+
+
+@settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture, HealthCheck.data_too_large, HealthCheck.large_base_example])
+@given(object_arrays(max_objects=400))
+def test_larger_degenerate_scenes_f64_bit_exact(rt, oracle, objs):
+    _check(rt, oracle, objs)
