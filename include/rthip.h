@@ -242,7 +242,8 @@ int32_t rthip_bvh_gate_count(const rthip_object* objects, int64_t n, int64_t* n_
 int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* violations, int32_t* n_nodes, int32_t* depth,
                            uint64_t* checksum);
 
-/* The same checks on the tree a context holds on the device, downloaded for the purpose: the one
+/* (No counterpart in the reference either.)  The same checks on the tree a context holds on the
+ * device, downloaded for the purpose: the one
  * rthip_scene_upload built on the host, or, with the build option "tree_gpu", the linear BVH the
  * GPU built (Morton codes, radix sort, hierarchy and boxes in kernels; the pass over the
  * reference's tree that yields tie ranks and gates stays on the host).  Any output pointer may be NULL. */
