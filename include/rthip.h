@@ -121,6 +121,15 @@ int32_t rthip_set_option(rthip_ctx* ctx, const char* name, double value);
  * tree on the host, flattens it and uploads nodes, primitives and materials to HBM.
  * n == 0 -> RTHIP_ERR_EMPTY. */
 int32_t rthip_scene_upload(rthip_ctx* ctx, const rthip_object* objects, int64_t n);
+/* No counterpart in the reference, whose scenes never change once BVH::new has run (src/bvh.rs:17-81
+ * is its only builder); for callers that move objects between frames.  `objects` are the objects of
+ * the last rthip_scene_upload in the same order, at new places, sizes or materials: the same count,
+ * each still a sphere or still a cube, the same ones impossible to hit (cubes with a negative half
+ * extent), else RTHIP_ERR_INVALID and the scene on the device stays as it was.  The device tree keeps its shape
+ * and its boxes are fitted again on the GPU, bottom up, one launch per level; tie ranks and gates are those
+ * of the reference's tree over the objects as they now are, so every result equals that of a fresh
+ * upload.  Far-reaching moves leave a tree that is sound but slow to walk: upload then. */
+int32_t rthip_scene_refit(rthip_ctx* ctx, const rthip_object* objects, int64_t n);
 /* Replaces Camera::new (src/camera.rs:25-69).  Changing the image size resets the
  * accumulation buffer; changing only the pose does not (callers reset, as
  * raytracer_runtime/src/main.rs:101-103,149 does). */

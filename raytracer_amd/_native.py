@@ -51,6 +51,7 @@ SYMBOLS = {
     "rthip_set_stream": (C.c_int32, [_P, _P]),
     "rthip_set_option": (C.c_int32, [_P, C.c_char_p, C.c_double]),
     "rthip_scene_upload": (C.c_int32, [_P, _P, C.c_int64]),
+    "rthip_scene_refit": (C.c_int32, [_P, _P, C.c_int64]),
     "rthip_camera_set": (C.c_int32, [_P, C.POINTER(CameraDesc)]),
     "rthip_camera_fields": (C.c_int32, [C.POINTER(CameraDesc), C.POINTER(C.c_double)]),
     "rthip_render_accumulate": (C.c_int32, [_P, C.POINTER(RenderParams)]),

@@ -200,6 +200,16 @@ class Renderer:
         self._upload(scene)
         self.reset_accumulation()
 
+    def refit_scene(self, scene):
+        """The same objects at new places (rthip_scene_refit): the device tree keeps its shape, its
+        boxes are fitted again on the GPU; results equal those of a fresh upload.  Accumulation
+        cleared, camera kept.  Raises when the objects are not the ones the tree was built over."""
+        objs = scene.objects if isinstance(scene, Scene) else scene.scene.objects
+        objs = np.ascontiguousarray(objs, dtype=N.OBJECT_DTYPE)
+        self._check(self._lib.rthip_scene_refit(self._ctx, objs.ctypes.data, len(objs)))
+        self._objs = objs
+        self.reset_accumulation()
+
     def _raise(self, code):
         msg = self._lib.rthip_last_error(self._ctx)
         raise N.RthipError(code, msg.decode() if msg else "")

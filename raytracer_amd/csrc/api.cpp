@@ -202,6 +202,42 @@ int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const st
 }
 
 
+// Refit: everything behind the nodes of a blob (primitives, gates, materials) replaced, the nodes
+// kept.  In place when the new arrays lie where the old ones did (the number of gate boxes can
+// change when objects move); otherwise into a new allocation that the nodes are copied into.
+template <typename Real>
+int32_t replace_blob_tail(rthip_ctx* c, size_t n_nodes, const std::vector<Prim<Real>>& prims, const std::vector<Mat<Real>>& mats,
+                          const std::vector<Gate<Real>>& gates, SceneBlob* b) {
+	const uint64_t nb = n_nodes * sizeof(Node<Real>), pb = prims.size() * sizeof(Prim<Real>), mb = mats.size() * sizeof(Mat<Real>);
+	const uint64_t gb = gates.size() * sizeof(Gate<Real>);
+	const uint64_t prims_off = align_up(nb, 64), gates_off = align_up(prims_off + pb, 64), mats_off = align_up(gates_off + gb, 64);
+	const uint64_t qb = b->qnodes_off ? n_nodes * sizeof(QNode) : 0;
+	const uint64_t q_off = align_up(mats_off + mb, 64);
+	const uint64_t total = align_up(q_off + qb, 64);
+	if (total > 0xFFFFFFF0ull) return fail(c, RTHIP_ERR_LIMIT, "scene larger than 4 GiB");
+	if (prims_off != b->prims_off) return fail(c, RTHIP_ERR_INTERNAL, "refit: the primitives moved");
+	std::vector<char> host((size_t)(q_off - prims_off), 0);
+	std::memcpy(host.data(), prims.data(), (size_t)pb);
+	if (gb) std::memcpy(host.data() + (gates_off - prims_off), gates.data(), (size_t)gb);
+	std::memcpy(host.data() + (mats_off - prims_off), mats.data(), (size_t)mb);
+	const bool same_place = gates_off == b->gates_off && mats_off == b->mats_off && total == b->bytes && (!qb || q_off == b->qnodes_off);
+	if (!same_place) {
+		char* fresh = nullptr;
+		HIP_TRY(c, hipMalloc(&fresh, (size_t)total));
+		hipError_t e = hipMemcpy(fresh, b->dev, (size_t)nb, hipMemcpyDeviceToDevice);
+		if (e == hipSuccess && qb) e = hipMemset(fresh + q_off, 0, (size_t)qb);
+		if (e != hipSuccess) { (void)hipFree(fresh); HIP_TRY(c, e); }
+		HIP_TRY(c, hipFree(b->dev));
+		b->dev = fresh;
+		b->gates_off = (uint32_t)gates_off; b->mats_off = (uint32_t)mats_off; b->bytes = (uint32_t)total;
+		if (qb) b->qnodes_off = (uint32_t)q_off;
+		b->lds_bytes = (uint32_t)mats_off;
+		b->lds_bytes_mats = align_up(mats_off + mb, 64);
+	}
+	HIP_TRY(c, hipMemcpy(b->dev + prims_off, host.data(), host.size(), hipMemcpyHostToDevice));
+	return RTHIP_OK;
+}
+
 // Scenes up to this size are copied into LDS by every workgroup of the render kernel.
 constexpr uint32_t kLdsSceneLimit = 64 * 1024;
 constexpr int kWfMaxDepth = 4096;
@@ -683,6 +719,49 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 		c->n_gates = (int)flat.gates32.size();
 		c->n_objects = n;
 		c->stats.n_nodes = c->n_nodes; c->stats.n_leaves = c->n_leaves; c->stats.n_prims = c->n_prims; c->stats.tree_depth = c->tree_depth;
+		c->stats.n_gates = c->n_gates;
+		c->has_scene = true;
+		return RTHIP_OK;
+	});
+}
+
+int32_t rthip_scene_refit(rthip_ctx* c, const rthip_object* objects, int64_t n) {
+	if (!c) return RTHIP_ERR_INVALID;
+	return guarded(c, [&]() -> int32_t {
+		if (!c->has_scene) return fail(c, RTHIP_ERR_STATE, "upload a scene first");
+		if (n < 0 || (n > 0 && !objects)) return fail(c, RTHIP_ERR_INVALID, "objects is NULL or n < 0");
+		if (n != c->n_objects) return fail(c, RTHIP_ERR_INVALID, "refit: the scene on the device has " + std::to_string(c->n_objects) + " objects, not " + std::to_string(n) + " (upload the scene instead)");
+		HIP_TRY(c, hipSetDevice(c->device));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		// which object sits in which place of the device tree's primitive array
+		std::vector<int32_t> slot_ids((size_t)c->n_prims);
+		HIP_TRY(c, gpu_slot_ids(c->blob32.dev, c->blob32.prims_off, c->n_prims, slot_ids.data(), c->stream));
+		FlatScene flat;
+		std::string err;
+		if (!refit_flat_scene(objects, n, slot_ids.data(), (int64_t)slot_ids.size(), &flat, &err, c->build_opt)) return fail(c, RTHIP_ERR_INVALID, err);
+		// From here on the device holds a mixture of old and new until the last step has run.
+		c->has_scene = false;
+		int32_t rc = replace_blob_tail<float>(c, (size_t)c->n_nodes, flat.prims32, flat.mats32, flat.gates32, &c->blob32);
+		if (rc != RTHIP_OK) return rc;
+		rc = replace_blob_tail<double>(c, (size_t)c->n_nodes, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
+		if (rc != RTHIP_OK) return rc;
+		GpuRefitIO io{};
+		io.blob32 = c->blob32.dev; io.blob64 = c->blob64.dev;
+		io.prims_off32 = c->blob32.prims_off; io.prims_off64 = c->blob64.prims_off; io.qnodes_off32 = c->blob32.qnodes_off;
+		io.n_nodes = c->n_nodes; io.levels = c->tree_depth;
+		io.big_leaf = c->big_leaf != 0;
+		io.quantise = c->blob32.qnodes_off != 0;
+		GpuRefitResult res{};
+		const auto t0 = std::chrono::steady_clock::now();
+		HIP_TRY(c, gpu_refit_tree(io, c->stream, &res));
+		if (c->build_opt.timing)
+			std::fprintf(stderr, "[rthip build] %-28s %.3f s\n", "refit (on the GPU)", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+		if (res.unreached) return fail(c, RTHIP_ERR_INTERNAL, "refit: " + std::to_string(res.unreached) + " nodes of the device tree are not below its root");
+		if (io.quantise) {
+			if (res.quantised) { for (int k = 0; k < 3; k++) { c->blob32.qframe.centre[k] = res.frame.centre[k]; c->blob32.qframe.step[k] = res.frame.step[k]; } }
+			else c->blob32.qnodes_off = 0;
+		}
+		c->n_gates = (int)flat.gates32.size();
 		c->stats.n_gates = c->n_gates;
 		c->has_scene = true;
 		return RTHIP_OK;

@@ -243,6 +243,57 @@ __global__ void quantise_kernel(GpuBuildIO io, QFrame f, int32_t first_node, int
 	reinterpret_cast<QNode*>(io.blob32 + io.qnodes_off32)[i] = q;
 }
 
+// ---- refit ------------------------------------------------------------------------------
+// Level of every inner node below node 0, one launch per level from the top: a node of level L
+// labels its inner children L + 1.
+__global__ void refit_label_kernel(int32_t n_nodes, const Node<float>* n32, int level, int32_t* node_level) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	if (i >= n_nodes || node_level[i] != level) return;
+	for (int c = 0; c < 2; c++) {
+		const int32_t child = n32[i].child[c];
+		if (child >= 0 && child < n_nodes) node_level[child] = level + 1;
+	}
+}
+__global__ void refit_unreached_kernel(int32_t n_nodes, const int32_t* node_level, int32_t* unreached) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	if (i < n_nodes && node_level[i] < 0) atomicAdd(unreached, 1);
+}
+// Every node of level `level` (deepest level first): the box of each child, from the leaf's
+// primitives as they now are or from what the inner child kept in the launch before, into the
+// node in both precisions; their union is kept for the parent.
+__global__ void refit_fit_kernel(GpuRefitIO io, int level, const int32_t* node_level, Box6* node_b64, Box6* node_b32) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	if (i >= io.n_nodes || node_level[i] != level) return;
+	Node<float>* n32 = reinterpret_cast<Node<float>*>(io.blob32);
+	Node<double>* n64 = reinterpret_cast<Node<double>*>(io.blob64);
+	const Prim<float>* p32 = reinterpret_cast<const Prim<float>*>(io.blob32 + io.prims_off32);
+	const Prim<double>* p64 = reinterpret_cast<const Prim<double>*>(io.blob64 + io.prims_off64);
+	Box6 u64, u32;
+	for (int side = 0; side < 2; side++) {
+		const int32_t child = n32[i].child[side];
+		Box6 b64, b32;
+		if (child >= 0) {
+			b64 = node_b64[child]; b32 = node_b32[child];
+		} else {
+			const uint32_t code = ~(uint32_t)child;
+			const uint32_t first = code >> 6, count = ((code >> 3) & 7u) + (code & 7u);
+			for (int k = 0; k < 3; k++) { b64.lo[k] = b32.lo[k] = INFINITY; b64.hi[k] = b32.hi[k] = -INFINITY; }  // an empty leaf keeps this
+			for (uint32_t j = first; j < first + count; j++) {
+				Box6 a64, a32;
+				prim_bounds(p64[j], p32[j], &a64, &a32);
+				box_join(&b64, a64); box_join(&b32, a32);
+			}
+		}
+		store_child_box(&n32[i], &n64[i], side, b64, b32);
+		if (side == 0) { u64 = b64; u32 = b32; } else { box_join(&u64, b64); box_join(&u32, b32); }
+	}
+	node_b64[i] = u64; node_b32[i] = u32;
+}
+__global__ void slot_ids_kernel(const Prim<float>* p32, int32_t n, int32_t* ids) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	if (i < n) ids[i] = p32[i].id;
+}
+
 struct Scratch {  // device memory of one build, freed when it goes out of scope
 	std::vector<void*> ptrs;
 	~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
@@ -259,6 +310,22 @@ struct Scratch {  // device memory of one build, freed when it goes out of scope
 #define GB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
 }  // namespace
+
+// The grid of the quantised nodes: it spans the tree's own bounds as node 0 holds them (the leaf of
+// oversized primitives, node 0's left child when there is one, stays outside it).
+static void frame_from_root(const Node<float>& node0, bool big_leaf, QFrame* f) {
+	for (int k = 0; k < 3; k++) {
+		double lo = DBL_MAX, hi = -DBL_MAX;
+		for (int c = big_leaf ? 1 : 0; c < 2; c++) {
+			const float centre = node0.box[6 * c + kLoSlot[k]], half = node0.box[6 * c + kHiSlot[k]];
+			if (half < 0.0f) continue;
+			lo = std::fmin(lo, (double)centre - (double)half); hi = std::fmax(hi, (double)centre + (double)half);
+		}
+		f->centre[k] = (float)(0.5 * (lo + hi));
+		const double half = std::fmax(hi - (double)f->centre[k], (double)f->centre[k] - lo);
+		f->step[k] = (float)std::fmax(half / (kQMax - 64), 1e-30);  // headroom for the outward rounding
+	}
+}
 
 hipError_t gpu_build_tree(const GpuBuildIO& io_in, hipStream_t stream, GpuBuildResult* res) {
 	GpuBuildIO io = io_in;
@@ -314,19 +381,8 @@ hipError_t gpu_build_tree(const GpuBuildIO& io_in, hipStream_t stream, GpuBuildR
 	GB_TRY(hipMemcpyAsync(&node0, io.blob32, sizeof(node0), hipMemcpyDeviceToHost, stream));
 	GB_TRY(hipStreamSynchronize(stream));
 	if (io.quantise) {
-		// the grid spans the tree's own bounds (the leaf of oversized primitives stays outside it)
 		QFrame& f = res->frame;
-		for (int k = 0; k < 3; k++) {
-			double lo = DBL_MAX, hi = -DBL_MAX;
-			for (int c = (io.node_base == 1 ? 1 : 0); c < 2; c++) {
-				const float centre = node0.box[6 * c + kLoSlot[k]], half = node0.box[6 * c + kHiSlot[k]];
-				if (half < 0.0f) continue;
-				lo = std::fmin(lo, (double)centre - (double)half); hi = std::fmax(hi, (double)centre + (double)half);
-			}
-			f.centre[k] = (float)(0.5 * (lo + hi));
-			const double half = std::fmax(hi - (double)f.centre[k], (double)f.centre[k] - lo);
-			f.step[k] = (float)std::fmax(half / (kQMax - 64), 1e-30);  // headroom for the outward rounding
-		}
+		frame_from_root(node0, io.node_base == 1, &f);
 		f.start = io.node_base;
 		f.big_leaf = 0;  // the caller knows the leaf's code
 		const int first_node = io.node_base;
@@ -338,6 +394,68 @@ hipError_t gpu_build_tree(const GpuBuildIO& io_in, hipStream_t stream, GpuBuildR
 		res->quantised = over == 0;
 	}
 	return hipSuccess;
+}
+
+hipError_t gpu_refit_tree(const GpuRefitIO& io, hipStream_t stream, GpuRefitResult* res) {
+	if (io.n_nodes < 1 || io.levels < 1 || io.levels > kStackMax) return hipErrorInvalidValue;
+	Scratch mem;
+	const size_t nn = (size_t)io.n_nodes;
+	int32_t *node_level, *flags;
+	Box6 *node_b64, *node_b32;
+	GB_TRY(mem.get(&node_level, nn)); GB_TRY(mem.get(&node_b64, nn)); GB_TRY(mem.get(&node_b32, nn)); GB_TRY(mem.get(&flags, 2));
+	GB_TRY(hipMemsetAsync(node_level, 0xff, nn * sizeof(int32_t), stream));
+	GB_TRY(hipMemsetAsync(node_level, 0, sizeof(int32_t), stream));  // node 0 is level 0
+	GB_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), stream));
+	const unsigned grid = (unsigned)((nn + kBlock - 1) / kBlock);
+	const Node<float>* n32 = reinterpret_cast<const Node<float>*>(io.blob32);
+	for (int level = 0; level + 1 < io.levels; level++) {
+		hipLaunchKernelGGL(refit_label_kernel, dim3(grid), dim3(kBlock), 0, stream, io.n_nodes, n32, level, node_level);
+		GB_TRY(hipGetLastError());
+	}
+	hipLaunchKernelGGL(refit_unreached_kernel, dim3(grid), dim3(kBlock), 0, stream, io.n_nodes, node_level, flags);
+	GB_TRY(hipGetLastError());
+	int32_t unreached = 0;
+	GB_TRY(hipMemcpyAsync(&unreached, flags, sizeof(unreached), hipMemcpyDeviceToHost, stream));
+	GB_TRY(hipStreamSynchronize(stream));
+	res->unreached = unreached;
+	res->quantised = false;
+	if (unreached) return hipSuccess;
+	for (int level = io.levels - 1; level >= 0; level--) {
+		hipLaunchKernelGGL(refit_fit_kernel, dim3(grid), dim3(kBlock), 0, stream, io, level, node_level, node_b64, node_b32);
+		GB_TRY(hipGetLastError());
+	}
+	if (io.quantise) {
+		Node<float> node0;
+		GB_TRY(hipMemcpyAsync(&node0, io.blob32, sizeof(node0), hipMemcpyDeviceToHost, stream));
+		GB_TRY(hipStreamSynchronize(stream));
+		frame_from_root(node0, io.big_leaf, &res->frame);
+		GpuBuildIO q{};
+		q.blob32 = io.blob32; q.qnodes_off32 = io.qnodes_off32; q.n_nodes = io.n_nodes;
+		const int first_node = io.big_leaf ? 1 : 0;
+		if (io.n_nodes > first_node) {
+			hipLaunchKernelGGL(quantise_kernel, dim3((unsigned)((io.n_nodes - first_node + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, q, res->frame, first_node, flags + 1);
+			GB_TRY(hipGetLastError());
+		}
+		int over = 0;
+		GB_TRY(hipMemcpyAsync(&over, flags + 1, sizeof(over), hipMemcpyDeviceToHost, stream));
+		GB_TRY(hipStreamSynchronize(stream));
+		res->quantised = over == 0;
+	} else {
+		GB_TRY(hipStreamSynchronize(stream));
+	}
+	return hipSuccess;
+}
+
+hipError_t gpu_slot_ids(const char* blob32, uint32_t prims_off32, int32_t n_prims, int32_t* host_ids, hipStream_t stream) {
+	if (n_prims < 1) return hipErrorInvalidValue;
+	Scratch mem;
+	int32_t* ids;
+	GB_TRY(mem.get(&ids, (size_t)n_prims));
+	hipLaunchKernelGGL(slot_ids_kernel, dim3((unsigned)((n_prims + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+	                   reinterpret_cast<const Prim<float>*>(blob32 + prims_off32), n_prims, ids);
+	GB_TRY(hipGetLastError());
+	GB_TRY(hipMemcpyAsync(host_ids, ids, (size_t)n_prims * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+	return hipStreamSynchronize(stream);
 }
 
 }  // namespace rthip

@@ -311,6 +311,7 @@ struct Builder {
 
 	struct RefNode { size_t begin, end; int left, right; Box ref; };
 	std::vector<RefNode> ref_nodes;
+	int ref_root = 0;
 	std::vector<int32_t> rank;        // per object id
 	std::vector<uint32_t> gate_first, gate_count;  // per object id: index of its first gate box and how many it has (0 = none)
 
@@ -572,6 +573,32 @@ struct Builder {
 	}
 	// Appends the primitives ids[0..k) as one leaf: spheres first, then cubes, so the leaf loop
 	// has no per-primitive type branch.
+	// Appends the primitive of object `id` in both precisions.
+	void emit_prim(int32_t id) {
+		const rthip_object& o = objs[id];
+		Prim<double> p64;
+		Prim<float> p32;
+		for (int q = 0; q < 6; q++) { p64.v[q] = 0.0; p32.v[q] = 0.0f; }
+		for (int q = 0; q < 3; q++) { p64.v[q] = o.center[q]; p32.v[q] = (float)o.center[q]; }
+		if (o.kind == RTHIP_SPHERE) {
+			p64.v[3] = o.extent[0];
+			p32.v[3] = (float)o.extent[0];
+			// the sphere's gates, as integers in the two spare slots
+			prim_set_gates(p64, gate_first[(size_t)id], gate_count[(size_t)id]);
+			prim_set_gates(p32, gate_first[(size_t)id], gate_count[(size_t)id]);
+		} else {
+			for (int q = 0; q < 3; q++) {
+				p64.v[3 + q] = o.extent[q];
+				static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
+				p32.v[lo_slot[q]] = (float)(o.center[q] - o.extent[q]);
+				p32.v[hi_slot[q]] = (float)(o.center[q] + o.extent[q]);
+			}
+		}
+		p64.id = p32.id = id | (o.material << kMatShift) | (o.kind << kKindShift);
+		p64.rank = p32.rank = rank[(size_t)id];
+		prims64().push_back(p64);
+		prims32().push_back(p32);
+	}
 	Sub emit_leaf(const int32_t* ids, int k) {
 		int32_t first = (int32_t)prims64().size();
 		Box b64 = empty_box(), b32 = empty_box();
@@ -579,31 +606,9 @@ struct Builder {
 		for (int pass = 0; pass < 2; pass++) {
 			for (int j = 0; j < k; j++) {
 				int32_t id = ids[j];
-				const rthip_object& o = objs[id];
-				if ((o.kind == RTHIP_SPHERE) != (pass == 0)) continue;
+				if ((objs[id].kind == RTHIP_SPHERE) != (pass == 0)) continue;
 				if (pass == 0) ns++; else nc++;
-				Prim<double> p64;
-				Prim<float> p32;
-				for (int q = 0; q < 6; q++) { p64.v[q] = 0.0; p32.v[q] = 0.0f; }
-				for (int q = 0; q < 3; q++) { p64.v[q] = o.center[q]; p32.v[q] = (float)o.center[q]; }
-				if (o.kind == RTHIP_SPHERE) {
-					p64.v[3] = o.extent[0];
-					p32.v[3] = (float)o.extent[0];
-					// the sphere's gates, as integers in the two spare slots
-					prim_set_gates(p64, gate_first[(size_t)id], gate_count[(size_t)id]);
-					prim_set_gates(p32, gate_first[(size_t)id], gate_count[(size_t)id]);
-				} else {
-					for (int q = 0; q < 3; q++) {
-						p64.v[3 + q] = o.extent[q];
-						static const int lo_slot[3] = {kBoxLoX, kBoxLoY, kBoxLoZ}, hi_slot[3] = {kBoxHiX, kBoxHiY, kBoxHiZ};
-						p32.v[lo_slot[q]] = (float)(o.center[q] - o.extent[q]);
-						p32.v[hi_slot[q]] = (float)(o.center[q] + o.extent[q]);
-					}
-				}
-				p64.id = p32.id = id | (o.material << kMatShift) | (o.kind << kKindShift);
-				p64.rank = p32.rank = rank[(size_t)id];
-				prims64().push_back(p64);
-				prims32().push_back(p32);
+				emit_prim(id);
 				b64 = box_union(b64, bounds64(id));
 				b32 = box_union(b32, bounds32(id));
 			}
@@ -780,7 +785,12 @@ BuildOptions BuildOptions::from_env() {
 	return o;
 }
 
-bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err, const BuildOptions& opt) {
+namespace {
+// What every build starts with: the input checked, the materials by object id, and the reference's
+// tree (src/bvh.rs:17-81) with what depends on it: tie ranks, leaf order, gates, its depth.
+bool reference_pass(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err, const BuildOptions& opt, Builder* bp,
+                    const std::function<void(const char*)>& lap) {
+	Builder& b = *bp;
 	*out = FlatScene();
 	if (n <= 0) { *err = "empty scene: BVH::new returns None"; return false; }
 	if (n > kMaxObjects) { *err = "too many objects"; return false; }
@@ -790,7 +800,6 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		for (int k = 0; k < 3; k++) ok = ok && std::isfinite(o.center[k]) && std::isfinite(o.albedo[k]) && (o.kind == RTHIP_SPHERE ? std::isfinite(o.extent[0]) : std::isfinite(o.extent[k]));
 		if (!ok) { *err = "object " + std::to_string(i) + " has an invalid kind, material or a non-finite field"; return false; }
 	}
-	Builder b;
 	b.objs = objs;
 	b.n_objs = n;
 	b.out = out;
@@ -806,18 +815,10 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		out->mats64[(size_t)i].param = objs[i].param;
 		out->mats32[(size_t)i].param = (float)objs[i].param;
 	}
-	const bool timing = opt.timing;
-	auto t_start = std::chrono::steady_clock::now();
-	auto lap = [&](const char* what) {
-		if (!timing) return;
-		auto now = std::chrono::steady_clock::now();
-		std::fprintf(stderr, "[rthip build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_start).count());
-		t_start = now;
-	};
-	// 1. the reference's tree: ranks, leaf order, gates
 	b.threads_on = opt.threads;
 	b.tie_reverse = opt.tie_reverse;
 	int ref_root = b.ref_build(0, (size_t)n);
+	b.ref_root = ref_root;
 	lap("reference tree");
 	{
 		std::vector<int> chain;
@@ -837,6 +838,35 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		out->ref_depth = d;
 	}
 	lap("ranks, gates, depth");
+	return true;
+}
+// Materials in primitive order: shading reads the record of the primitive that was hit without a
+// trip through the primitive's object id, and small scenes keep the array in LDS beside the primitives.
+void materials_in_primitive_order(FlatScene* out) {
+	std::vector<Mat<float>> m32(out->prims32.size());
+	std::vector<Mat<double>> m64(out->prims64.size());
+	for (size_t i = 0; i < out->prims32.size(); i++) {
+		const size_t id = (size_t)(out->prims32[i].id & ((1 << kMatShift) - 1));
+		m32[i] = out->mats32[id];
+		m64[i] = out->mats64[id];
+	}
+	out->mats32.swap(m32);
+	out->mats64.swap(m64);
+}
+}  // namespace
+
+bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err, const BuildOptions& opt) {
+	Builder b;
+	const bool timing = opt.timing;
+	auto t_start = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if (!timing) return;
+		auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "[rthip build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_start).count());
+		t_start = now;
+	};
+	if (!reference_pass(objs, n, out, err, opt, &b, lap)) return false;
+	const int ref_root = b.ref_root;
 	// 2. the device tree
 	bool use_sah = !opt.tree_ref;
 	b.max_leaf = std::max(1, std::min(7, opt.sah_leaf));
@@ -1020,19 +1050,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		}
 	}
 	lap("device tree");
-	// materials in primitive order: shading reads the record of the primitive that was hit without a
-	// trip through the primitive's object id, and small scenes keep the array in LDS beside the primitives
-	{
-		std::vector<Mat<float>> m32(out->prims32.size());
-		std::vector<Mat<double>> m64(out->prims64.size());
-		for (size_t i = 0; i < out->prims32.size(); i++) {
-			const size_t id = (size_t)(out->prims32[i].id & ((1 << kMatShift) - 1));
-			m32[i] = out->mats32[id];
-			m64[i] = out->mats64[id];
-		}
-		out->mats32.swap(m32);
-		out->mats64.swap(m64);
-	}
+	materials_in_primitive_order(out);
 	if (out->gpu.on) return true;  // depth, start and the quantised nodes come from the device build
 	out->depth = std::max(1, b.max_depth);
 	if (use_sah && !big_ids_empty) { out->big_leaf = out->nodes32[0].child[0]; out->start = out->nodes32[0].child[1]; }
@@ -1087,6 +1105,26 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 		}
 		if (!ok) out->qnodes.clear();  // cannot happen with the headroom above; the full nodes are always valid
 	}
+	return true;
+}
+
+bool refit_flat_scene(const rthip_object* objs, int64_t n, const int32_t* slot_ids, int64_t n_slots, FlatScene* out, std::string* err, const BuildOptions& opt) {
+	Builder b;
+	if (!reference_pass(objs, n, out, err, opt, &b, [](const char*) {})) return false;
+	int64_t hittable = 0;
+	for (int64_t i = 0; i < n; i++) hittable += b.can_be_hit((int32_t)i) ? 1 : 0;
+	if (hittable != n_slots) { *err = "refit: " + std::to_string(hittable) + " objects can be hit, the tree holds " + std::to_string(n_slots) + " (upload the scene instead)"; return false; }
+	std::vector<bool> seen((size_t)n, false);
+	for (int64_t s = 0; s < n_slots; s++) {
+		const int32_t old = slot_ids[s], id = old & ((1 << kMatShift) - 1);
+		if (id < 0 || id >= n || seen[(size_t)id] || !b.can_be_hit(id) || ((old >> kKindShift) & 1) != objs[id].kind) {
+			*err = "refit: object " + std::to_string(id) + " is not the kind of primitive the tree holds in its place, or can no longer be hit (upload the scene instead)";
+			return false;
+		}
+		seen[(size_t)id] = true;
+		b.emit_prim(id);
+	}
+	materials_in_primitive_order(out);
 	return true;
 }
 

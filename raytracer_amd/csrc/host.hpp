@@ -76,6 +76,12 @@ struct BuildOptions {
 };
 // Returns false (with a message) for an empty scene or non-finite input.
 bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err, const BuildOptions& opt);
+// The same objects at new places, for a device tree that keeps its shape: `slot_ids` holds the id
+// words (Prim::id) of that tree's primitives in their order on the device.  Fills in primitives (with
+// the tie ranks and gates of the reference's tree over the NEW places), gates and materials in that
+// order and no nodes.  Returns false when the objects are not the ones the tree was built over: another
+// count of objects that can be hit, or another kind of primitive in some place.
+bool refit_flat_scene(const rthip_object* objs, int64_t n, const int32_t* slot_ids, int64_t n_slots, FlatScene* out, std::string* err, const BuildOptions& opt);
 // Checks the invariant every culling decision rests on: each f32 child box (centre and half
 // extent), and each quantised one, contains the f32 bounds of every primitive below it; every
 // primitive that can be hit is in exactly one leaf; the tree is no deeper than reported.

@@ -72,6 +72,7 @@ unsafe extern "C" {
     fn rthip_last_error(ctx: *const RthipCtx) -> *const c_char;
     fn rthip_set_option(ctx: *mut RthipCtx, name: *const c_char, value: f64) -> i32;
     fn rthip_scene_upload(ctx: *mut RthipCtx, objects: *const RthipObject, n: i64) -> i32;
+    fn rthip_scene_refit(ctx: *mut RthipCtx, objects: *const RthipObject, n: i64) -> i32;
     fn rthip_camera_set(ctx: *mut RthipCtx, cam: *const RthipCameraDesc) -> i32;
     fn rthip_render_accumulate(ctx: *mut RthipCtx, p: *const RthipRenderParams) -> i32;
     fn rthip_render_accumulate_async(ctx: *mut RthipCtx, p: *const RthipRenderParams) -> i32;
@@ -159,6 +160,14 @@ impl HipRenderer {
         let r = Self { ctx, width: 0, height: 0, spp_done: 0, max_depth, seed };
         check(ctx, unsafe { rthip_scene_upload(ctx, objs.as_ptr(), objs.len() as i64) })?; // on error `r` drops and frees the context
         Ok(r)
+    }
+
+    /// The same objects at new places: the tree on the GPU keeps its shape and has its boxes fitted again
+    /// (rthip_scene_refit; the reference has no counterpart, its scenes are static).  Resets the accumulation.
+    pub fn refit(&mut self, scene: &Scene) -> Result<(), String> {
+        let objs = objects(scene);
+        check(self.ctx, unsafe { rthip_scene_refit(self.ctx, objs.as_ptr(), objs.len() as i64) })?;
+        self.reset_accumulation()
     }
 
     /// Tuning or build knob by name (see rthip_set_option in include/rthip.h).

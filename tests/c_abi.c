@@ -75,6 +75,14 @@ int main(int argc, char** argv) {
 		EXPECT(bad == 0 && dev_nodes == st.n_nodes && dev_depth == st.tree_depth);
 	}
 	EXPECT(st.paths == 64u * 40u * 3u && st.rays >= st.paths);
+	/* refit with the objects where they are: the same tree, the same image (compared below) */
+	OK(rthip_scene_refit(ctx, objs, n));
+	EXPECT(rthip_scene_refit(ctx, objs, n - 1) == RTHIP_ERR_INVALID);
+	{
+		int64_t bad = -1;
+		OK(rthip_scene_validate(ctx, &bad, NULL, NULL));
+		EXPECT(bad == 0);
+	}
 	void* dptr = NULL;
 	uint64_t words = 0;
 	OK(rthip_accum_buffer(ctx, &dptr, &words));
