@@ -110,7 +110,8 @@ int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
  * "scene_lds", "qnodes", "threads", "blocks_per_cu", "grid_reserve", "chunk", "trav_threshold", "inner_exit",
  * "regen_min", "block_order", "wf_batch", "count" take effect with the next render call; build
  * knobs "tree_ref" (1 = device tree in the reference's shape), "tree_gpu" (1 = device tree built
- * on the GPU, a linear BVH with "gpu_leaf" primitives per leaf), "sah_leaf", "sah_kind_cap" (at most so many
+ * on the GPU, a linear BVH with "gpu_leaf" primitives per leaf), "ref_gpu" (tie ranks, gates and primitive
+ * records made on the GPU for such uploads and for refits: 1 always, 0 never, -1 = from 2048 objects on), "sah_leaf", "sah_kind_cap" (at most so many
  * spheres and so many cubes per leaf, 0 = no cap), "sah_cprim",
  * "sah_sweep", "big_leaf_min", "no_big_leaf", "no_qnodes", "build_threads", "tie_reverse"
  * (1 = equal sort keys of BVH::new in reversed order, see rthip_bvh_leaf_order) with the next
@@ -254,8 +255,9 @@ int32_t rthip_bvh_validate(const rthip_object* objects, int64_t n, int64_t* viol
 /* (No counterpart in the reference either.)  The same checks on the tree a context holds on the
  * device, downloaded for the purpose: the one
  * rthip_scene_upload built on the host, or, with the build option "tree_gpu", the linear BVH the
- * GPU built (Morton codes, radix sort, hierarchy and boxes in kernels; the pass over the
- * reference's tree that yields tie ranks and gates stays on the host).  Any output pointer may be NULL. */
+ * GPU built (Morton codes, radix sort, hierarchy and boxes in kernels; the tie ranks and gates that
+ * hang on the reference's tree come from level-by-level segmented sorts on the GPU as well, see the
+ * option "ref_gpu").  Any output pointer may be NULL. */
 int32_t rthip_scene_validate(rthip_ctx* ctx, int64_t* violations, int32_t* n_nodes, int32_t* depth);
 
 /* Seeded scene factories (no GPU needed).  Same distributions as the reference's factories,

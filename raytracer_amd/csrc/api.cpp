@@ -238,6 +238,58 @@ int32_t replace_blob_tail(rthip_ctx* c, size_t n_nodes, const std::vector<Prim<R
 	return RTHIP_OK;
 }
 
+// A blob of the given shape, allocated and zeroed, nothing in it yet (the device makes the contents).
+template <typename Real>
+int32_t alloc_blob(rthip_ctx* c, size_t n_nodes, size_t n_prims, size_t n_gates, bool with_qnodes, SceneBlob* b) {
+	const uint64_t nb = n_nodes * sizeof(Node<Real>), pb = n_prims * sizeof(Prim<Real>), mb = n_prims * sizeof(Mat<Real>), gb = n_gates * sizeof(Gate<Real>);
+	const uint64_t prims_off = align_up(nb, 64), gates_off = align_up(prims_off + pb, 64), mats_off = align_up(gates_off + gb, 64);
+	const uint64_t qb = with_qnodes ? n_nodes * sizeof(QNode) : 0;
+	const uint64_t q_off = align_up(mats_off + mb, 64);
+	const uint64_t total = align_up(q_off + qb, 64);
+	if (total > 0xFFFFFFF0ull) return fail(c, RTHIP_ERR_LIMIT, "scene larger than 4 GiB");
+	if (b->dev) { HIP_TRY(c, hipFree(b->dev)); b->dev = nullptr; }
+	HIP_TRY(c, hipMalloc(&b->dev, (size_t)total));
+	HIP_TRY(c, hipMemset(b->dev, 0, (size_t)total));
+	b->prims_off = (uint32_t)prims_off; b->mats_off = (uint32_t)mats_off; b->gates_off = (uint32_t)gates_off; b->bytes = (uint32_t)total;
+	b->qnodes_off = qb ? (uint32_t)q_off : 0u;
+	b->lds_bytes = (uint32_t)mats_off;
+	b->lds_bytes_mats = align_up(mats_off + mb, 64);
+	return RTHIP_OK;
+}
+// Refit on the device: room for another number of gate boxes.  Nodes and primitives are copied
+// across (the primitives still name the objects in their places); gates and materials are rewritten anyway.
+template <typename Real>
+int32_t regate_blob(rthip_ctx* c, size_t n_nodes, size_t n_prims, size_t n_gates, SceneBlob* b) {
+	const uint64_t pb = n_prims * sizeof(Prim<Real>), mb = n_prims * sizeof(Mat<Real>), gb = n_gates * sizeof(Gate<Real>);
+	const uint64_t gates_off = b->gates_off, mats_off = align_up(gates_off + gb, 64);
+	if (mats_off == b->mats_off) return RTHIP_OK;
+	const uint64_t qb = b->qnodes_off ? n_nodes * sizeof(QNode) : 0;
+	const uint64_t q_off = align_up(mats_off + mb, 64);
+	const uint64_t total = align_up(q_off + qb, 64);
+	if (total > 0xFFFFFFF0ull) return fail(c, RTHIP_ERR_LIMIT, "scene larger than 4 GiB");
+	char* fresh = nullptr;
+	HIP_TRY(c, hipMalloc(&fresh, (size_t)total));
+	hipError_t e = hipMemset(fresh, 0, (size_t)total);
+	if (e == hipSuccess) e = hipMemcpy(fresh, b->dev, (size_t)(b->prims_off + pb), hipMemcpyDeviceToDevice);
+	if (e != hipSuccess) { (void)hipFree(fresh); HIP_TRY(c, e); }
+	HIP_TRY(c, hipFree(b->dev));
+	b->dev = fresh;
+	b->mats_off = (uint32_t)mats_off; b->bytes = (uint32_t)total;
+	if (qb) b->qnodes_off = (uint32_t)q_off;
+	b->lds_bytes = (uint32_t)mats_off;
+	b->lds_bytes_mats = align_up(mats_off + mb, 64);
+	return RTHIP_OK;
+}
+// Whether ranks, gates and primitive records of a scene of n objects are made on the device (see BuildOptions::ref_gpu).
+bool reference_pass_on_device(const BuildOptions& o, int64_t n) {
+	if (o.tie_reverse) return false;  // the other tie order is the host pass's knob
+	return o.ref_gpu > 0 || (o.ref_gpu < 0 && n >= 2048);
+}
+struct RefPassHolder {  // frees the device arrays of a reference pass on every way out
+	GpuRefPass ref;
+	~RefPassHolder() { ref.release(); }
+};
+
 // Scenes up to this size are copied into LDS by every workgroup of the render kernel.
 constexpr uint32_t kLdsSceneLimit = 64 * 1024;
 constexpr int kWfMaxDepth = 4096;
@@ -663,6 +715,7 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		else if (k == "count") t.count = iv;
 		else if (k == "tree_ref") b.tree_ref = iv != 0;
 		else if (k == "tree_gpu") b.tree_gpu = iv != 0;
+		else if (k == "ref_gpu") b.ref_gpu = iv;
 		else if (k == "gpu_leaf") b.gpu_leaf = iv;
 		else if (k == "sah_leaf") b.sah_leaf = iv;
 		else if (k == "sah_kind_cap") b.sah_kind_cap = iv;
@@ -687,12 +740,59 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		FlatScene flat;
 		std::string err;
-		if (!build_flat_scene(objects, n, &flat, &err, c->build_opt)) return fail(c, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
-		c->has_scene = false;
-		int32_t rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32, &flat.qnodes, &flat.qframe);
-		if (rc != RTHIP_OK) return rc;
-		rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
-		if (rc != RTHIP_OK) return rc;
+		int32_t rc = RTHIP_OK;
+		int64_t n_prims = 0, n_gates = 0;
+		bool on_device = false;
+		if (c->build_opt.tree_gpu && reference_pass_on_device(c->build_opt, n)) {
+			// Everything that hangs on the objects is made on the device: the host checks them, picks the
+			// oversized ones and says which object goes where (host.cpp); tie ranks and gates, primitive and
+			// material records (refpass_gpu.hip) and the tree (build_gpu.hip) are the GPU's.
+			const auto t0 = std::chrono::steady_clock::now();
+			std::vector<int32_t> slot_ids;
+			if (!plan_device_scene(objects, n, &flat, &slot_ids, &err, c->build_opt)) return fail(c, RTHIP_ERR_INVALID, err);
+			if (flat.gpu.on) {
+				RefPassHolder h;
+				HIP_TRY(c, gpu_reference_pass(objects, n, c->stream, &h.ref));
+				c->has_scene = false;
+				n_prims = (int64_t)slot_ids.size(); n_gates = h.ref.n_gates;
+				rc = alloc_blob<float>(c, flat.nodes32.size(), (size_t)n_prims, (size_t)n_gates, !flat.qnodes.empty(), &c->blob32);
+				if (rc != RTHIP_OK) return rc;
+				rc = alloc_blob<double>(c, flat.nodes64.size(), (size_t)n_prims, (size_t)n_gates, false, &c->blob64);
+				if (rc != RTHIP_OK) return rc;
+				if (flat.gpu.node_base == 1) {  // node 0: the leaf of oversized primitives on the left, the tree to come on the right
+					HIP_TRY(c, hipMemcpy(c->blob32.dev, flat.nodes32.data(), sizeof(Node<float>), hipMemcpyHostToDevice));
+					HIP_TRY(c, hipMemcpy(c->blob64.dev, flat.nodes64.data(), sizeof(Node<double>), hipMemcpyHostToDevice));
+				}
+				if (n_gates) {
+					HIP_TRY(c, hipMemcpy(c->blob32.dev + c->blob32.gates_off, h.ref.gates32, (size_t)n_gates * sizeof(Gate<float>), hipMemcpyDeviceToDevice));
+					HIP_TRY(c, hipMemcpy(c->blob64.dev + c->blob64.gates_off, h.ref.gates64, (size_t)n_gates * sizeof(Gate<double>), hipMemcpyDeviceToDevice));
+				}
+				int32_t* d_ids = nullptr;
+				HIP_TRY(c, hipMalloc(&d_ids, slot_ids.size() * sizeof(int32_t)));
+				hipError_t e = hipMemcpy(d_ids, slot_ids.data(), slot_ids.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+				if (e == hipSuccess)
+					e = gpu_emit_prims(h.ref, d_ids, 1, (int32_t)n_prims, reinterpret_cast<Prim<float>*>(c->blob32.dev + c->blob32.prims_off),
+					                   reinterpret_cast<Prim<double>*>(c->blob64.dev + c->blob64.prims_off), reinterpret_cast<Mat<float>*>(c->blob32.dev + c->blob32.mats_off),
+					                   reinterpret_cast<Mat<double>*>(c->blob64.dev + c->blob64.mats_off), c->stream);
+				if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+				(void)hipFree(d_ids);
+				HIP_TRY(c, e);
+				flat.n_leaves = (int)ref_tree_leaves(n);
+				flat.ref_depth = std::max(1, ref_tree_levels(n));
+				on_device = true;
+				if (c->build_opt.timing)
+					std::fprintf(stderr, "[rthip build] %-28s %.3f s\n", "layout, ranks, gates (GPU)", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+			}
+		}
+		if (!on_device) {
+			if (!build_flat_scene(objects, n, &flat, &err, c->build_opt)) return fail(c, flat.depth > kStackMax ? RTHIP_ERR_LIMIT : RTHIP_ERR_INVALID, err);
+			c->has_scene = false;
+			rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32, &flat.qnodes, &flat.qframe);
+			if (rc != RTHIP_OK) return rc;
+			rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
+			if (rc != RTHIP_OK) return rc;
+			n_prims = (int64_t)flat.prims32.size(); n_gates = (int64_t)flat.gates32.size();
+		}
 		if (flat.gpu.on) {
 			// the tree over the laid-out primitives is built on the device (build_gpu.hip)
 			const FlatScene::GpuPlan& g = flat.gpu;
@@ -715,8 +815,8 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 			else c->blob32.qnodes_off = 0;
 		}
 		c->big_leaf = flat.big_leaf; c->start = flat.start;
-		c->tree_depth = flat.depth; c->n_nodes = (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)flat.prims32.size();
-		c->n_gates = (int)flat.gates32.size();
+		c->tree_depth = flat.depth; c->n_nodes = (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)n_prims;
+		c->n_gates = (int)n_gates;
 		c->n_objects = n;
 		c->stats.n_nodes = c->n_nodes; c->stats.n_leaves = c->n_leaves; c->stats.n_prims = c->n_prims; c->stats.tree_depth = c->tree_depth;
 		c->stats.n_gates = c->n_gates;
@@ -733,18 +833,56 @@ int32_t rthip_scene_refit(rthip_ctx* c, const rthip_object* objects, int64_t n) 
 		if (n != c->n_objects) return fail(c, RTHIP_ERR_INVALID, "refit: the scene on the device has " + std::to_string(c->n_objects) + " objects, not " + std::to_string(n) + " (upload the scene instead)");
 		HIP_TRY(c, hipSetDevice(c->device));
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
-		// which object sits in which place of the device tree's primitive array
-		std::vector<int32_t> slot_ids((size_t)c->n_prims);
-		HIP_TRY(c, gpu_slot_ids(c->blob32.dev, c->blob32.prims_off, c->n_prims, slot_ids.data(), c->stream));
-		FlatScene flat;
 		std::string err;
-		if (!refit_flat_scene(objects, n, slot_ids.data(), (int64_t)slot_ids.size(), &flat, &err, c->build_opt)) return fail(c, RTHIP_ERR_INVALID, err);
-		// From here on the device holds a mixture of old and new until the last step has run.
-		c->has_scene = false;
-		int32_t rc = replace_blob_tail<float>(c, (size_t)c->n_nodes, flat.prims32, flat.mats32, flat.gates32, &c->blob32);
-		if (rc != RTHIP_OK) return rc;
-		rc = replace_blob_tail<double>(c, (size_t)c->n_nodes, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
-		if (rc != RTHIP_OK) return rc;
+		int32_t rc = RTHIP_OK;
+		int64_t n_gates = 0;
+		const auto t_start = std::chrono::steady_clock::now();
+		if (reference_pass_on_device(c->build_opt, n)) {
+			// ranks, gates and the primitive records on the device; the id words of the primitives the
+			// tree holds say which object goes where
+			if (!check_scene_objects(objects, n, &err)) return fail(c, RTHIP_ERR_INVALID, err);
+			const int64_t hittable = count_hittable(objects, n);
+			if (hittable != c->n_prims)
+				return fail(c, RTHIP_ERR_INVALID, "refit: " + std::to_string(hittable) + " objects can be hit, the tree holds " + std::to_string(c->n_prims) + " (upload the scene instead)");
+			RefPassHolder h;
+			HIP_TRY(c, gpu_reference_pass(objects, n, c->stream, &h.ref));
+			const int32_t* id_words = reinterpret_cast<const int32_t*>(c->blob32.dev + c->blob32.prims_off + offsetof(Prim<float>, id));
+			constexpr int32_t kIdStride = (int32_t)(sizeof(Prim<float>) / sizeof(int32_t));
+			int32_t other = 0;
+			HIP_TRY(c, gpu_same_objects(h.ref, id_words, kIdStride, c->n_prims, &other, c->stream));
+			if (other) return fail(c, RTHIP_ERR_INVALID, "refit: " + std::to_string(other) + " objects are not the kind of primitive the tree holds in their place, or can no longer be hit (upload the scene instead)");
+			// From here on the device holds a mixture of old and new until the last step has run.
+			c->has_scene = false;
+			n_gates = h.ref.n_gates;
+			rc = regate_blob<float>(c, (size_t)c->n_nodes, (size_t)c->n_prims, (size_t)n_gates, &c->blob32);
+			if (rc != RTHIP_OK) return rc;
+			rc = regate_blob<double>(c, (size_t)c->n_nodes, (size_t)c->n_prims, (size_t)n_gates, &c->blob64);
+			if (rc != RTHIP_OK) return rc;
+			if (n_gates) {
+				HIP_TRY(c, hipMemcpy(c->blob32.dev + c->blob32.gates_off, h.ref.gates32, (size_t)n_gates * sizeof(Gate<float>), hipMemcpyDeviceToDevice));
+				HIP_TRY(c, hipMemcpy(c->blob64.dev + c->blob64.gates_off, h.ref.gates64, (size_t)n_gates * sizeof(Gate<double>), hipMemcpyDeviceToDevice));
+			}
+			id_words = reinterpret_cast<const int32_t*>(c->blob32.dev + c->blob32.prims_off + offsetof(Prim<float>, id));
+			HIP_TRY(c, gpu_emit_prims(h.ref, id_words, kIdStride, c->n_prims, reinterpret_cast<Prim<float>*>(c->blob32.dev + c->blob32.prims_off),
+			                          reinterpret_cast<Prim<double>*>(c->blob64.dev + c->blob64.prims_off), reinterpret_cast<Mat<float>*>(c->blob32.dev + c->blob32.mats_off),
+			                          reinterpret_cast<Mat<double>*>(c->blob64.dev + c->blob64.mats_off), c->stream));
+			HIP_TRY(c, hipStreamSynchronize(c->stream));
+		} else {
+			// which object sits in which place of the device tree's primitive array
+			std::vector<int32_t> slot_ids((size_t)c->n_prims);
+			HIP_TRY(c, gpu_slot_ids(c->blob32.dev, c->blob32.prims_off, c->n_prims, slot_ids.data(), c->stream));
+			FlatScene flat;
+			if (!refit_flat_scene(objects, n, slot_ids.data(), (int64_t)slot_ids.size(), &flat, &err, c->build_opt)) return fail(c, RTHIP_ERR_INVALID, err);
+			// From here on the device holds a mixture of old and new until the last step has run.
+			c->has_scene = false;
+			rc = replace_blob_tail<float>(c, (size_t)c->n_nodes, flat.prims32, flat.mats32, flat.gates32, &c->blob32);
+			if (rc != RTHIP_OK) return rc;
+			rc = replace_blob_tail<double>(c, (size_t)c->n_nodes, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
+			if (rc != RTHIP_OK) return rc;
+			n_gates = (int64_t)flat.gates32.size();
+		}
+		if (c->build_opt.timing)
+			std::fprintf(stderr, "[rthip build] %-28s %.3f s\n", "refit: ranks, gates, records", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
 		GpuRefitIO io{};
 		io.blob32 = c->blob32.dev; io.blob64 = c->blob64.dev;
 		io.prims_off32 = c->blob32.prims_off; io.prims_off64 = c->blob64.prims_off; io.qnodes_off32 = c->blob32.qnodes_off;
@@ -761,7 +899,7 @@ int32_t rthip_scene_refit(rthip_ctx* c, const rthip_object* objects, int64_t n) 
 			if (res.quantised) { for (int k = 0; k < 3; k++) { c->blob32.qframe.centre[k] = res.frame.centre[k]; c->blob32.qframe.step[k] = res.frame.step[k]; } }
 			else c->blob32.qnodes_off = 0;
 		}
-		c->n_gates = (int)flat.gates32.size();
+		c->n_gates = (int)n_gates;
 		c->stats.n_gates = c->n_gates;
 		c->has_scene = true;
 		return RTHIP_OK;

@@ -49,4 +49,28 @@ hipError_t gpu_refit_tree(const GpuRefitIO& io, hipStream_t stream, GpuRefitResu
 // The id words (Prim::id) of the primitives in their order on the device, into host memory.
 hipError_t gpu_slot_ids(const char* blob32, uint32_t prims_off32, int32_t n_prims, int32_t* host_ids, hipStream_t stream);
 
+// ---- what hangs on the reference's tree, computed on the device (refpass_gpu.hip) ---------------
+struct GpuRefPass {  // device arrays; the holder calls release()
+	rthip_object* objs = nullptr;  // the objects as the caller gave them
+	int32_t n = 0;
+	int32_t* rank = nullptr;                               // per object id: tie rank
+	uint32_t *gate_first = nullptr, *gate_count = nullptr;  // per object id: its gate boxes in the arrays below, 0 and 0 for none
+	Gate<double>* gates64 = nullptr;
+	Gate<float>* gates32 = nullptr;
+	int64_t n_gates = 0;
+	void release();
+};
+// Inner-node levels on the longest path of the reference's tree over n objects, and its number of
+// leaves: both follow from n alone (src/bvh.rs:52,62: leaves of fewer than six, splits at len / 2).
+int ref_tree_levels(int64_t n);
+int64_t ref_tree_leaves(int64_t n);
+// Copies the objects to the device and computes tie ranks and gates there.  The objects must have
+// been checked (finite fields, known kinds).  Runs on `stream` and waits for it; about 250 bytes of scratch per object.
+hipError_t gpu_reference_pass(const rthip_object* host_objs, int64_t n, hipStream_t stream, GpuRefPass* out);
+// The primitive and the material of object (dev_ids[s * id_stride] & id mask) into slot s of the four
+// arrays; the ids may be the id words of those very primitives (stride 8 from &p32[0].id).
+hipError_t gpu_emit_prims(const GpuRefPass& ref, const int32_t* dev_ids, int32_t id_stride, int32_t count, Prim<float>* p32, Prim<double>* p64, Mat<float>* m32, Mat<double>* m64, hipStream_t stream);
+// Refit: counts the slots whose id word (dev_slot_ids[s * id_stride], a Prim::id) names an object that is now of another kind or can no longer be hit.
+hipError_t gpu_same_objects(const GpuRefPass& ref, const int32_t* dev_slot_ids, int32_t id_stride, int32_t count, int32_t* mismatches, hipStream_t stream);
+
 }  // namespace rthip

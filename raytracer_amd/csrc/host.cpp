@@ -771,6 +771,7 @@ struct Builder {
 BuildOptions BuildOptions::from_env() {
 	BuildOptions o;
 	if (const char* v = std::getenv("RTHIP_TREE")) { o.tree_ref = std::string(v) == "ref"; o.tree_gpu = std::string(v) == "gpu"; }
+	if (const char* v = std::getenv("RTHIP_REF_GPU")) o.ref_gpu = std::atoi(v);
 	if (const char* v = std::getenv("RTHIP_GPU_LEAF")) o.gpu_leaf = std::atoi(v);
 	if (const char* v = std::getenv("RTHIP_SAH_LEAF")) o.sah_leaf = std::atoi(v);
 	if (const char* v = std::getenv("RTHIP_SAH_KIND_CAP")) o.sah_kind_cap = std::atoi(v);
@@ -786,12 +787,7 @@ BuildOptions BuildOptions::from_env() {
 }
 
 namespace {
-// What every build starts with: the input checked, the materials by object id, and the reference's
-// tree (src/bvh.rs:17-81) with what depends on it: tie ranks, leaf order, gates, its depth.
-bool reference_pass(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err, const BuildOptions& opt, Builder* bp,
-                    const std::function<void(const char*)>& lap) {
-	Builder& b = *bp;
-	*out = FlatScene();
+bool check_objects(const rthip_object* objs, int64_t n, std::string* err) {
 	if (n <= 0) { *err = "empty scene: BVH::new returns None"; return false; }
 	if (n > kMaxObjects) { *err = "too many objects"; return false; }
 	for (int64_t i = 0; i < n; i++) {
@@ -800,6 +796,15 @@ bool reference_pass(const rthip_object* objs, int64_t n, FlatScene* out, std::st
 		for (int k = 0; k < 3; k++) ok = ok && std::isfinite(o.center[k]) && std::isfinite(o.albedo[k]) && (o.kind == RTHIP_SPHERE ? std::isfinite(o.extent[0]) : std::isfinite(o.extent[k]));
 		if (!ok) { *err = "object " + std::to_string(i) + " has an invalid kind, material or a non-finite field"; return false; }
 	}
+	return true;
+}
+// What every build starts with: the input checked, the materials by object id, and the reference's
+// tree (src/bvh.rs:17-81) with what depends on it: tie ranks, leaf order, gates, its depth.
+bool reference_pass(const rthip_object* objs, int64_t n, FlatScene* out, std::string* err, const BuildOptions& opt, Builder* bp,
+                    const std::function<void(const char*)>& lap) {
+	Builder& b = *bp;
+	*out = FlatScene();
+	if (!check_objects(objs, n, err)) return false;
 	b.objs = objs;
 	b.n_objs = n;
 	b.out = out;
@@ -838,6 +843,88 @@ bool reference_pass(const rthip_object* objs, int64_t n, FlatScene* out, std::st
 		out->ref_depth = d;
 	}
 	lap("ranks, gates, depth");
+	return true;
+}
+// Build option tree_gpu: the primitives laid out for the device build (the leaf of oversized
+// primitives first, spheres before cubes; every other primitive behind it, spheres before cubes, in
+// object order), the nodes reserved, node 0 written if there is such a leaf, the box of the
+// centres.  With `slot_ids` the primitives are not written, only listed (object id per place):
+// the caller makes them on the device.  False (and nothing done) for scenes of fewer than two leaves.
+bool layout_for_device_build(Builder& b, const BuildOptions& opt, std::vector<int32_t>* slot_ids) {
+	FlatScene* out = b.out;
+	const rthip_object* objs = b.objs;
+	const int64_t n = b.n_objs;
+	const int leaf_size = std::max(1, std::min(7, opt.gpu_leaf));
+	std::vector<int32_t> rest, big;
+	for (int64_t i = 0; i < n; i++) if (b.can_be_hit((int32_t)i)) rest.push_back((int32_t)i);
+	// the same few oversized primitives the surface-area build keeps out of its tree
+	auto diag = [&](int32_t id) {
+		Box bb = b.bounds64(id);
+		double dx = bb.hi[0] - bb.lo[0], dy = bb.hi[1] - bb.lo[1], dz = bb.hi[2] - bb.lo[2];
+		return std::sqrt(dx * dx + dy * dy + dz * dz);
+	};
+	if (rest.size() > (size_t)std::max(0, opt.big_leaf_min) && !opt.no_big_leaf) {
+		std::vector<double> d(rest.size());
+		for (size_t i = 0; i < rest.size(); i++) d[i] = diag(rest[i]);
+		std::vector<double> all = d;
+		std::nth_element(d.begin(), d.begin() + (long)(d.size() / 2), d.end());
+		const double limit = 64.0 * d[d.size() / 2];
+		int ns = 0, nc = 0;
+		for (size_t i = 0; i < rest.size(); i++) if (all[i] > limit) { big.push_back(rest[i]); (objs[rest[i]].kind == RTHIP_SPHERE ? ns : nc)++; }
+		if (ns > 7 || nc > 7) big.clear();
+		if (!big.empty()) {
+			size_t keep = 0;
+			for (size_t i = 0; i < rest.size(); i++) if (!(all[i] > limit)) rest[keep++] = rest[i];
+			rest.resize(keep);
+		}
+	}
+	const size_t n_leaves = (rest.size() + (size_t)leaf_size - 1) / (size_t)leaf_size;
+	if (n_leaves < 2) return false;
+	// a leaf as emit_leaf makes it, or only listed
+	auto place = [&](const std::vector<int32_t>& ids, int32_t first) {
+		if (!slot_ids) return b.emit_leaf(ids.data(), (int)ids.size());
+		Builder::Sub sub{0, empty_box(), empty_box()};
+		int ns = 0, nc = 0;
+		for (int pass = 0; pass < 2; pass++)
+			for (int32_t id : ids) {
+				if ((objs[id].kind == RTHIP_SPHERE) != (pass == 0)) continue;
+				if (pass == 0) ns++; else nc++;
+				slot_ids->push_back(id);
+				sub.b64 = box_union(sub.b64, b.bounds64(id));
+				sub.b32 = box_union(sub.b32, b.bounds32(id));
+			}
+		sub.code = leaf_code(first, ns & 7, nc & 7);  // (only the leaf of oversized primitives is used as a leaf: at most 7 of each)
+		return sub;
+	};
+	FlatScene::GpuPlan& g = out->gpu;
+	g.on = true;
+	g.leaf_size = leaf_size;
+	g.n_leaves = (int32_t)n_leaves;
+	g.node_base = big.empty() ? 0 : 1;
+	const size_t n_nodes = (size_t)g.node_base + n_leaves - 1;
+	out->nodes64.assign(n_nodes, Node<double>{});
+	out->nodes32.assign(n_nodes, Node<float>{});
+	if (!big.empty()) {
+		Builder::Sub r;
+		r.code = leaf_code(0, 0, 0);
+		r.b64 = r.b32 = empty_box();
+		Builder::Sub bl = place(big, 0);
+		b.write_node(0, bl, r);  // the right child is the device's to fill in
+		out->big_leaf = bl.code;
+		out->start = 1;
+	}
+	g.first = (int32_t)big.size();
+	g.count = (int32_t)rest.size();
+	(void)place(rest, g.first);  // every other primitive, spheres then cubes, in object order
+	double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+	for (int32_t id : rest)
+		for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], objs[id].center[k]); hi[k] = std::fmax(hi[k], objs[id].center[k]); }
+	// One scale for the three axes (the longest extent): the cells of the code are cubes, so a
+	// flat scene is not cut into slabs along its short axis (per-axis scales traced at half the rate).
+	const double extent = std::fmax(std::fmax(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+	for (int k = 0; k < 3; k++) { g.clo[k] = lo[k]; g.cinv[k] = extent > 0.0 ? 1.0 / extent : 0.0; }
+	g.quantise = n_nodes > 2048 && !opt.no_qnodes;
+	if (g.quantise) out->qnodes.assign(n_nodes, QNode{});
 	return true;
 }
 // Materials in primitive order: shading reads the record of the primitive that was hit without a
@@ -879,57 +966,7 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 	r.code = leaf_code(0, 0, 0);
 	r.b64 = r.b32 = empty_box();
 	// 2a. tree_gpu: lay the primitives out and leave the tree to the device
-	if (opt.tree_gpu) {
-		const int leaf_size = std::max(1, std::min(7, opt.gpu_leaf));
-		std::vector<int32_t> rest, big;
-		for (int64_t i = 0; i < n; i++) if (b.can_be_hit((int32_t)i)) rest.push_back((int32_t)i);
-		// the same few oversized primitives the surface-area build keeps out of its tree
-		auto diag = [&](int32_t id) {
-			Box bb = b.bounds64(id);
-			double dx = bb.hi[0] - bb.lo[0], dy = bb.hi[1] - bb.lo[1], dz = bb.hi[2] - bb.lo[2];
-			return std::sqrt(dx * dx + dy * dy + dz * dz);
-		};
-		if (rest.size() > (size_t)std::max(0, opt.big_leaf_min) && !opt.no_big_leaf) {
-			std::vector<double> d(rest.size());
-			for (size_t i = 0; i < rest.size(); i++) d[i] = diag(rest[i]);
-			std::nth_element(d.begin(), d.begin() + (long)(d.size() / 2), d.end());
-			const double limit = 64.0 * d[d.size() / 2];
-			int ns = 0, nc = 0;
-			for (int32_t id : rest) if (diag(id) > limit) { big.push_back(id); (objs[id].kind == RTHIP_SPHERE ? ns : nc)++; }
-			if (ns > 7 || nc > 7) big.clear();
-			if (!big.empty()) rest.erase(std::remove_if(rest.begin(), rest.end(), [&](int32_t id) { return diag(id) > limit; }), rest.end());
-		}
-		const size_t n_leaves = (rest.size() + (size_t)leaf_size - 1) / (size_t)leaf_size;
-		if (n_leaves >= 2) {
-			FlatScene::GpuPlan& g = out->gpu;
-			g.on = true;
-			g.leaf_size = leaf_size;
-			g.n_leaves = (int32_t)n_leaves;
-			g.node_base = big.empty() ? 0 : 1;
-			const size_t n_nodes = (size_t)g.node_base + n_leaves - 1;
-			out->nodes64.assign(n_nodes, Node<double>{});
-			out->nodes32.assign(n_nodes, Node<float>{});
-			if (!big.empty()) {
-				Builder::Sub bl = b.emit_leaf(big.data(), (int)big.size());
-				b.write_node(0, bl, r);  // the right child is the device's to fill in
-				out->big_leaf = bl.code;
-				out->start = 1;
-			}
-			g.first = (int32_t)out->prims64.size();
-			g.count = (int32_t)rest.size();
-			(void)b.emit_leaf(rest.data(), (int)rest.size());  // every other primitive, spheres then cubes, in object order
-			double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-			for (int32_t id : rest)
-				for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], objs[id].center[k]); hi[k] = std::fmax(hi[k], objs[id].center[k]); }
-			// One scale for the three axes (the longest extent): the cells of the code are cubes, so a
-			// flat scene is not cut into slabs along its short axis (per-axis scales traced at half the rate).
-			const double extent = std::fmax(std::fmax(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-			for (int k = 0; k < 3; k++) { g.clo[k] = lo[k]; g.cinv[k] = extent > 0.0 ? 1.0 / extent : 0.0; }
-			g.quantise = n_nodes > 2048 && !opt.no_qnodes;
-			if (g.quantise) out->qnodes.assign(n_nodes, QNode{});
-			lap("layout for the device build");
-		}
-	}
+	if (opt.tree_gpu && layout_for_device_build(b, opt, nullptr)) lap("layout for the device build");
 	if (out->gpu.on) {
 		// nothing more to build here
 	} else if (use_sah) {
@@ -1126,6 +1163,27 @@ bool refit_flat_scene(const rthip_object* objs, int64_t n, const int32_t* slot_i
 	}
 	materials_in_primitive_order(out);
 	return true;
+}
+
+bool plan_device_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::vector<int32_t>* slot_ids, std::string* err, const BuildOptions& opt) {
+	*out = FlatScene();
+	slot_ids->clear();
+	if (!check_objects(objs, n, err)) return false;
+	Builder b;
+	b.objs = objs;
+	b.n_objs = n;
+	b.out = out;
+	(void)layout_for_device_build(b, opt, slot_ids);
+	return true;
+}
+
+bool check_scene_objects(const rthip_object* objs, int64_t n, std::string* err) { return check_objects(objs, n, err); }
+
+int64_t count_hittable(const rthip_object* objs, int64_t n) {
+	int64_t k = 0;
+	for (int64_t i = 0; i < n; i++)
+		k += (objs[i].kind == RTHIP_SPHERE || (objs[i].extent[0] >= 0.0 && objs[i].extent[1] >= 0.0 && objs[i].extent[2] >= 0.0)) ? 1 : 0;
+	return k;
 }
 
 uint64_t checksum_flat_scene(const FlatScene& s) {

@@ -60,6 +60,9 @@ struct FlatScene {
 struct BuildOptions {
 	bool tree_ref = false;     // RTHIP_TREE=ref: the device tree keeps the reference's shape (default: surface-area build)
 	bool tree_gpu = false;     // RTHIP_TREE=gpu: the device tree is a linear BVH built on the GPU (scenes of at least two leaves; contexts only)
+	int ref_gpu = -1;          // RTHIP_REF_GPU: tie ranks and gates (what hangs on the reference's tree) and the primitive records made on the device,
+	                           // for uploads with tree_gpu and for refits: 1 = always, 0 = never (the host's pass), -1 = from 2048 objects on
+	                           // (below, the host is done before the device's launches are queued: 0.4 against 0.8 ms for 560 objects)
 	int gpu_leaf = 1;          // RTHIP_GPU_LEAF: primitives per leaf of that build, 1..7 (1 traces fastest: 1.4 against 0.5 Gpaths/s with 4 on a million objects)
 	int sah_leaf = 4;          // RTHIP_SAH_LEAF: largest leaf of the surface-area build, 1..7
 	int sah_kind_cap = 0;      // RTHIP_SAH_KIND_CAP: at most this many spheres and this many cubes per leaf, 0 = no cap
@@ -82,6 +85,16 @@ bool build_flat_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::
 // order and no nodes.  Returns false when the objects are not the ones the tree was built over: another
 // count of objects that can be hit, or another kind of primitive in some place.
 bool refit_flat_scene(const rthip_object* objs, int64_t n, const int32_t* slot_ids, int64_t n_slots, FlatScene* out, std::string* err, const BuildOptions& opt);
+// Build option tree_gpu with the reference's ranks and gates computed on the device as well: checks
+// the objects and lays the scene out as build_flat_scene does for the device build (gpu plan, nodes
+// reserved, node 0, leaf of oversized primitives) WITHOUT primitives, materials, ranks or gates;
+// slot_ids receives the object id of every primitive place.  out->gpu.on stays false for scenes of
+// fewer than two leaves (build those on the host).
+bool plan_device_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::vector<int32_t>* slot_ids, std::string* err, const BuildOptions& opt);
+// check_objects only (refit on the device)
+bool check_scene_objects(const rthip_object* objs, int64_t n, std::string* err);
+// Objects that can be hit at all (every sphere; cubes without a negative half extent).
+int64_t count_hittable(const rthip_object* objs, int64_t n);
 // Checks the invariant every culling decision rests on: each f32 child box (centre and half
 // extent), and each quantised one, contains the f32 bounds of every primitive below it; every
 // primitive that can be hit is in exactly one leaf; the tree is no deeper than reported.

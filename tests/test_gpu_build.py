@@ -15,7 +15,7 @@ def test_gpu_built_tree_f64_bit_exact(rt, oracle, scene):
     w, h = 160, 90
     sc = rt.Scene.generate(scene)
     cam = camera_args(scene, w, h, rt)
-    r = rt.Renderer(sc, rt.Camera(*cam), seed=11, precision=rt.F64, max_depth=12, options={"tree_gpu": 1, "gpu_leaf": 2})
+    r = rt.Renderer(sc, rt.Camera(*cam), seed=11, precision=rt.F64, max_depth=12, options={"tree_gpu": 1, "gpu_leaf": 2, "ref_gpu": 1})
     host = rt.Renderer(sc, rt.Camera(*cam), seed=11, precision=rt.F64, max_depth=12)
     s = r.stats()
     if len(sc) <= 2:       # a scene of one leaf is built on the host whatever the option says
@@ -123,7 +123,7 @@ def test_gpu_build_degenerate_layouts(rt, oracle, case):
         from test_gpu_configs import hollow_shells
         sc = hollow_shells(rt, 4000)
     cam = ((13.0, 4.0, 9.0), (-13.0, -3.0, -9.0), 25.0, 10.0, 0.1, 160, 90)
-    r = rt.Renderer(sc, rt.Camera(*cam), seed=21, precision=rt.F64, max_depth=8, options={"tree_gpu": 1})
+    r = rt.Renderer(sc, rt.Camera(*cam), seed=21, precision=rt.F64, max_depth=8, options={"tree_gpu": 1, "ref_gpu": 1})
     r.validate_tree()
     osc = oracle.OracleScene(sc.objects)
     desc = oracle.camera_desc(*cam)
@@ -133,3 +133,54 @@ def test_gpu_build_degenerate_layouts(rt, oracle, case):
     _, smp, cnt, _ = osc.render(desc, 2, 8, 21, oracle.TIGHT, samples=True)
     assert np.array_equal(r.render_samples(2), smp) and r.stats()["rays"] == cnt["rays"]
     r.close()
+
+
+@pytest.mark.parametrize("scene", ["default", "glass", "hollow", "same_centre", "synthetic:70001", "five"])
+def test_device_reference_pass_equals_host_pass(rt, scene):
+    """Tie ranks and gates computed on the device (level-by-level segmented sorts, the default with
+    tree_gpu) against the host's pass over the reference's tree (ref_gpu = 0): the same gate count, the
+    same image word for word in both precisions, after an upload and after a refit."""
+    from raytracer_amd import _native as N
+    if scene == "hollow":
+        from test_gpu_configs import hollow_shells
+        sc = hollow_shells(rt, 2500)
+    elif scene == "same_centre":     # every sort key equal: the order is what a stable sort leaves
+        sc = _objects(rt, np.tile([0.0, 1.0, 0.0], (300, 1)), np.linspace(0.05, 3.0, 300))
+        sc.objects["extent"][1::2, 0] *= -1.0
+        sc.objects["material"][:] = N.DIELECTRIC
+        sc.objects["param"][:] = 1.5
+    elif scene == "five":            # one leaf: no tree for the device to build, ranks by one sort
+        sc = rt.Scene(rt.Scene.generate("default").objects[1:6].copy())
+    else:
+        sc = rt.Scene.generate(scene, 0x5EED0001)
+    cam = ((13.0, 4.0, 9.0), (-13.0, -3.0, -9.0), 25.0, 10.0, 0.1, 160, 90)
+    g = np.random.default_rng(4)
+    new = rt.Scene(sc.objects.copy())
+    small = np.abs(new.objects["extent"]).max(axis=1) < 10.0
+    new.objects["center"][small] += g.normal(0.0, 0.2, (int(small.sum()), 3))
+
+    def images(r):
+        out = []
+        for precision in (rt.F32, rt.F64):
+            r.precision = precision
+            r.reset_accumulation()
+            r.accumulate(2, spp_begin=0)
+            _, n = r.accum_buffer()
+            w = np.zeros(n, dtype=np.uint64)
+            r._check(r._lib.rthip_accum_download(r._ctx, w.ctypes.data, n))
+            out.append(w)
+        return out
+
+    dev = rt.Renderer(sc, rt.Camera(*cam), seed=2, max_depth=8, options={"tree_gpu": 1, "ref_gpu": 1})
+    host = rt.Renderer(sc, rt.Camera(*cam), seed=2, max_depth=8, options={"tree_gpu": 1, "ref_gpu": 0})
+    for step in range(2):
+        a, b = dev.stats(), host.stats()
+        assert (a["n_gates"], a["n_leaves"], a["n_prims"], a["n_nodes"]) == (b["n_gates"], b["n_leaves"], b["n_prims"], b["n_nodes"])
+        dev.validate_tree()
+        for x, y in zip(images(dev), images(host)):
+            assert np.array_equal(x, y)
+        if step == 0:
+            dev.refit_scene(new)
+            host.refit_scene(new)
+    print(f"[device reference pass] {scene}: {a['n_gates']} gate boxes, {a['n_leaves']} reference leaves")
+    dev.close(); host.close()

@@ -64,12 +64,14 @@ def test_refit_where_the_objects_are_changes_nothing(rt, scene):
     r.close()
 
 
-@pytest.mark.parametrize("tree", ["host", "gpu", "ref"])
+@pytest.mark.parametrize("tree", ["host", "gpu", "ref", "host-hostpass"])
 @pytest.mark.parametrize("scene", ["default", "sample", "glass"])
 def test_refit_moved_objects_f64_bit_exact(rt, oracle, scene, tree):
+    """(ref_gpu: ranks, gates and primitive records made on the device, as scenes of 2048 objects
+    and more have them by default, or by the host's pass over the reference's tree.)"""
     sc = rt.Scene.generate(scene)
     cam = camera_args(scene, 160, 90, rt)
-    options = {"host": {}, "gpu": {"tree_gpu": 1}, "ref": {"tree_ref": 1}}[tree]
+    options = {"host": {"ref_gpu": 1}, "gpu": {"tree_gpu": 1, "ref_gpu": 1}, "ref": {"tree_ref": 1, "ref_gpu": 1}, "host-hostpass": {"ref_gpu": 0}}[tree]
     r = rt.Renderer(sc, rt.Camera(*cam), seed=17, precision=rt.F64, max_depth=12, options=options)
     shape = r.validate_tree()
     for step, spread in enumerate((0.05, 0.6)):   # a nudge, then a shuffle
@@ -80,13 +82,14 @@ def test_refit_moved_objects_f64_bit_exact(rt, oracle, scene, tree):
     r.close()
 
 
-@pytest.mark.parametrize("tree", ["host", "gpu"])
+@pytest.mark.parametrize("tree", ["host", "gpu", "host-hostpass"])
 def test_refit_large_scene_in_global_memory(rt, oracle, tree):
     """200 000 objects (quantised nodes).  One object leaves the old bounds by far, so the grid of
     the quantised nodes has to be laid out again."""
     sc = rt.Scene.generate("synthetic:200000", 0x5EED0001)
     cam = ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0, 128, 72)
-    r = rt.Renderer(sc, rt.Camera(*cam), seed=5, precision=rt.F64, max_depth=20, options={"tree_gpu": 1} if tree == "gpu" else {})
+    options = {"host": {}, "gpu": {"tree_gpu": 1}, "host-hostpass": {"ref_gpu": 0}}[tree]
+    r = rt.Renderer(sc, rt.Camera(*cam), seed=5, precision=rt.F64, max_depth=20, options=options)
     shape = r.validate_tree()
     assert r.stats()["scene_in_lds"] == 0
     new = moved(rt, sc, 7, 0.5)
@@ -95,7 +98,7 @@ def test_refit_large_scene_in_global_memory(rt, oracle, tree):
     assert r.validate_tree() == shape
     check_against_oracle(rt, oracle, r, new, cam, 5, 20, f32_bound=2e-3)
     # and back: the first image again
-    first = rt.Renderer(sc, rt.Camera(*cam), seed=5, max_depth=20, options={"tree_gpu": 1} if tree == "gpu" else {})
+    first = rt.Renderer(sc, rt.Camera(*cam), seed=5, max_depth=20, options=options)
     r.refit_scene(sc)
     r.precision = rt.F32
     assert np.array_equal(words(r), words(first))
@@ -108,7 +111,7 @@ def test_refit_with_another_number_of_gate_boxes(rt, oracle):
     from test_gpu_configs import hollow_shells
     sc = hollow_shells(rt, 3000)
     cam = ((13.0, 4.0, 9.0), (-13.0, -3.0, -9.0), 25.0, 10.0, 0.1, 160, 90)
-    r = rt.Renderer(sc, rt.Camera(*cam), seed=21, precision=rt.F64, max_depth=8)
+    r = rt.Renderer(sc, rt.Camera(*cam), seed=21, precision=rt.F64, max_depth=8, options={"ref_gpu": 1})
     gates = r.stats()["n_gates"]
     new = moved(rt, sc, 9, 0.3, resize=0.0)
     r.refit_scene(new)
@@ -119,11 +122,12 @@ def test_refit_with_another_number_of_gate_boxes(rt, oracle):
     r.close()
 
 
-def test_refit_turns_down_other_objects(rt):
+@pytest.mark.parametrize("ref_gpu", [0, 1])
+def test_refit_turns_down_other_objects(rt, ref_gpu):
     from raytracer_amd import _native as N
     sc = rt.Scene.generate("default")
     cam = camera_args("default", 96, 54, rt)
-    r = rt.Renderer(sc, rt.Camera(*cam), seed=1)
+    r = rt.Renderer(sc, rt.Camera(*cam), seed=1, options={"ref_gpu": ref_gpu})
     before = words(r)
     cube = int(np.flatnonzero(sc.objects["kind"] == N.CUBE)[1])
     sphere = int(np.flatnonzero(sc.objects["kind"] == N.SPHERE)[5])
