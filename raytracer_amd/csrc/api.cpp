@@ -747,17 +747,25 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 			// Everything that hangs on the objects is made on the device: the host checks them, picks the
 			// oversized ones and says which object goes where (host.cpp); tie ranks and gates, primitive and
 			// material records (refpass_gpu.hip) and the tree (build_gpu.hip) are the GPU's.
-			const auto t0 = std::chrono::steady_clock::now();
+			auto t0 = std::chrono::steady_clock::now();
+			const auto lap = [&](const char* what) {
+				if (!c->build_opt.timing) return;
+				const auto now = std::chrono::steady_clock::now();
+				std::fprintf(stderr, "[rthip build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t0).count());
+				t0 = now;
+			};
 			std::vector<int32_t> slot_ids;
 			if (!plan_device_scene(objects, n, &flat, &slot_ids, &err, c->build_opt)) return fail(c, RTHIP_ERR_INVALID, err);
+			lap("checks and layout (host)");
 			if (flat.gpu.on) {
 				RefPassHolder h;
 				HIP_TRY(c, gpu_reference_pass(objects, n, c->stream, &h.ref));
+				lap("copy, ranks, gates (GPU)");
 				c->has_scene = false;
 				n_prims = (int64_t)slot_ids.size(); n_gates = h.ref.n_gates;
-				rc = alloc_blob<float>(c, flat.nodes32.size(), (size_t)n_prims, (size_t)n_gates, !flat.qnodes.empty(), &c->blob32);
+				rc = alloc_blob<float>(c, (size_t)flat.gpu.n_nodes, (size_t)n_prims, (size_t)n_gates, flat.gpu.quantise, &c->blob32);
 				if (rc != RTHIP_OK) return rc;
-				rc = alloc_blob<double>(c, flat.nodes64.size(), (size_t)n_prims, (size_t)n_gates, false, &c->blob64);
+				rc = alloc_blob<double>(c, (size_t)flat.gpu.n_nodes, (size_t)n_prims, (size_t)n_gates, false, &c->blob64);
 				if (rc != RTHIP_OK) return rc;
 				if (flat.gpu.node_base == 1) {  // node 0: the leaf of oversized primitives on the left, the tree to come on the right
 					HIP_TRY(c, hipMemcpy(c->blob32.dev, flat.nodes32.data(), sizeof(Node<float>), hipMemcpyHostToDevice));
@@ -780,8 +788,7 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 				flat.n_leaves = (int)ref_tree_leaves(n);
 				flat.ref_depth = std::max(1, ref_tree_levels(n));
 				on_device = true;
-				if (c->build_opt.timing)
-					std::fprintf(stderr, "[rthip build] %-28s %.3f s\n", "layout, ranks, gates (GPU)", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+				lap("records (GPU)");
 			}
 		}
 		if (!on_device) {
@@ -801,7 +808,7 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 			io.prims_off32 = c->blob32.prims_off; io.mats_off32 = c->blob32.mats_off; io.qnodes_off32 = c->blob32.qnodes_off;
 			io.prims_off64 = c->blob64.prims_off; io.mats_off64 = c->blob64.mats_off;
 			io.first = g.first; io.count = g.count; io.leaf_size = g.leaf_size; io.n_leaves = g.n_leaves; io.node_base = g.node_base;
-			io.n_nodes = (int32_t)flat.nodes32.size();
+			io.n_nodes = g.n_nodes;
 			for (int k = 0; k < 3; k++) { io.clo[k] = g.clo[k]; io.cinv[k] = g.cinv[k]; }
 			io.quantise = g.quantise && c->blob32.qnodes_off != 0;
 			GpuBuildResult res{};
@@ -815,7 +822,7 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 			else c->blob32.qnodes_off = 0;
 		}
 		c->big_leaf = flat.big_leaf; c->start = flat.start;
-		c->tree_depth = flat.depth; c->n_nodes = (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)n_prims;
+		c->tree_depth = flat.depth; c->n_nodes = flat.gpu.on ? flat.gpu.n_nodes : (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)n_prims;
 		c->n_gates = (int)n_gates;
 		c->n_objects = n;
 		c->stats.n_nodes = c->n_nodes; c->stats.n_leaves = c->n_leaves; c->stats.n_prims = c->n_prims; c->stats.tree_depth = c->tree_depth;

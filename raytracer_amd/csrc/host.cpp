@@ -881,19 +881,21 @@ bool layout_for_device_build(Builder& b, const BuildOptions& opt, std::vector<in
 	const size_t n_leaves = (rest.size() + (size_t)leaf_size - 1) / (size_t)leaf_size;
 	if (n_leaves < 2) return false;
 	// a leaf as emit_leaf makes it, or only listed
-	auto place = [&](const std::vector<int32_t>& ids, int32_t first) {
+	auto place = [&](const std::vector<int32_t>& ids, int32_t first, bool as_leaf) {
 		if (!slot_ids) return b.emit_leaf(ids.data(), (int)ids.size());
 		Builder::Sub sub{0, empty_box(), empty_box()};
 		int ns = 0, nc = 0;
+		slot_ids->reserve(slot_ids->size() + ids.size());
 		for (int pass = 0; pass < 2; pass++)
 			for (int32_t id : ids) {
 				if ((objs[id].kind == RTHIP_SPHERE) != (pass == 0)) continue;
 				if (pass == 0) ns++; else nc++;
 				slot_ids->push_back(id);
+				if (!as_leaf) continue;  // only the leaf of oversized primitives is used as a leaf (code and boxes)
 				sub.b64 = box_union(sub.b64, b.bounds64(id));
 				sub.b32 = box_union(sub.b32, b.bounds32(id));
 			}
-		sub.code = leaf_code(first, ns & 7, nc & 7);  // (only the leaf of oversized primitives is used as a leaf: at most 7 of each)
+		if (as_leaf) sub.code = leaf_code(first, ns, nc);
 		return sub;
 	};
 	FlatScene::GpuPlan& g = out->gpu;
@@ -902,20 +904,22 @@ bool layout_for_device_build(Builder& b, const BuildOptions& opt, std::vector<in
 	g.n_leaves = (int32_t)n_leaves;
 	g.node_base = big.empty() ? 0 : 1;
 	const size_t n_nodes = (size_t)g.node_base + n_leaves - 1;
-	out->nodes64.assign(n_nodes, Node<double>{});
-	out->nodes32.assign(n_nodes, Node<float>{});
+	g.n_nodes = (int32_t)n_nodes;
+	// (listing only: the nodes are the device's to allocate; the host composes node 0 alone)
+	out->nodes64.assign(slot_ids ? 1 : n_nodes, Node<double>{});
+	out->nodes32.assign(slot_ids ? 1 : n_nodes, Node<float>{});
 	if (!big.empty()) {
 		Builder::Sub r;
 		r.code = leaf_code(0, 0, 0);
 		r.b64 = r.b32 = empty_box();
-		Builder::Sub bl = place(big, 0);
+		Builder::Sub bl = place(big, 0, true);
 		b.write_node(0, bl, r);  // the right child is the device's to fill in
 		out->big_leaf = bl.code;
 		out->start = 1;
 	}
 	g.first = (int32_t)big.size();
 	g.count = (int32_t)rest.size();
-	(void)place(rest, g.first);  // every other primitive, spheres then cubes, in object order
+	(void)place(rest, g.first, false);  // every other primitive, spheres then cubes, in object order
 	double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
 	for (int32_t id : rest)
 		for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], objs[id].center[k]); hi[k] = std::fmax(hi[k], objs[id].center[k]); }
@@ -924,7 +928,7 @@ bool layout_for_device_build(Builder& b, const BuildOptions& opt, std::vector<in
 	const double extent = std::fmax(std::fmax(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
 	for (int k = 0; k < 3; k++) { g.clo[k] = lo[k]; g.cinv[k] = extent > 0.0 ? 1.0 / extent : 0.0; }
 	g.quantise = n_nodes > 2048 && !opt.no_qnodes;
-	if (g.quantise) out->qnodes.assign(n_nodes, QNode{});
+	if (g.quantise && !slot_ids) out->qnodes.assign(n_nodes, QNode{});
 	return true;
 }
 // Materials in primitive order: shading reads the record of the primitive that was hit without a

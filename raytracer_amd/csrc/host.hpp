@@ -50,6 +50,7 @@ struct FlatScene {
 	struct GpuPlan {
 		bool on = false;
 		int32_t first = 0, count = 0, leaf_size = 1, n_leaves = 0, node_base = 0;
+		int32_t n_nodes = 0;  // node_base + n_leaves - 1 (plan_device_scene keeps only node 0 on the host)
 		double clo[3] = {0, 0, 0}, cinv[3] = {0, 0, 0};  // box of the primitive centres: low corner, 1 / extent
 		bool quantise = false;
 	} gpu;

@@ -48,11 +48,12 @@ def check_against_oracle(rt, oracle, r, sc, cam, seed, depth, f32_bound=2e-4):
     assert (r.trace_primary(rt.F32, jitter=True, sample=1)[0] != ref[0]).mean() <= f32_bound
 
 
-@pytest.mark.parametrize("scene", SCENES)
-def test_refit_where_the_objects_are_changes_nothing(rt, scene):
-    sc = rt.Scene.generate(scene)
-    cam = camera_args(scene, 160, 90, rt)
-    r = rt.Renderer(sc, rt.Camera(*cam), seed=3, max_depth=10)
+@pytest.mark.parametrize("ref_gpu", [0, 1])
+@pytest.mark.parametrize("scene", SCENES + ["one"])
+def test_refit_where_the_objects_are_changes_nothing(rt, scene, ref_gpu):
+    sc = rt.Scene(rt.Scene.generate("simple").objects[:1].copy()) if scene == "one" else rt.Scene.generate(scene)
+    cam = camera_args("simple" if scene == "one" else scene, 160, 90, rt)
+    r = rt.Renderer(sc, rt.Camera(*cam), seed=3, max_depth=10, options={"ref_gpu": ref_gpu})
     r.set_option("count", 1)
     before = words(r)
     tests_before = r.stats()["box_tests"]
