@@ -822,6 +822,7 @@ bool reference_pass(const rthip_object* objs, int64_t n, FlatScene* out, std::st
 	}
 	b.threads_on = opt.threads;
 	b.tie_reverse = opt.tie_reverse;
+	if (opt.ranks_elsewhere && !opt.tree_ref) return true;  // the caller has ranks and gates from the device and rewrites the records
 	int ref_root = b.ref_build(0, (size_t)n);
 	b.ref_root = ref_root;
 	lap("reference tree");

@@ -76,6 +76,8 @@ struct BuildOptions {
 	bool timing = false;       // RTHIP_BUILD_TIMING: lap times on stderr
 	bool tie_reverse = false;  // RTHIP_TIE_REVERSE: objects with equal sort keys in BVH::new end up in reversed instead of
 	                           // kept order (sort_unstable_by, src/bvh.rs:49, leaves their order open)
+	bool ranks_elsewhere = false;  // not a knob: the caller computes tie ranks and gates on the device (refpass_gpu.hip) and rewrites the primitive
+	                               // records there, so the pass over the reference's tree is left out (ranks 0, no gates, no leaf order in the result)
 	static BuildOptions from_env();
 };
 // Returns false (with a message) for an empty scene or non-finite input.
