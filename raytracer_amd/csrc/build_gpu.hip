@@ -447,7 +447,7 @@ hipError_t gpu_refit_tree(const GpuRefitIO& io, hipStream_t stream, GpuRefitResu
 }
 
 hipError_t gpu_slot_ids(const char* blob32, uint32_t prims_off32, int32_t n_prims, int32_t* host_ids, hipStream_t stream) {
-	if (n_prims < 1) return hipErrorInvalidValue;
+	if (n_prims < 1) return hipSuccess;  // a scene in which nothing can be hit
 	Scratch mem;
 	int32_t* ids;
 	GB_TRY(mem.get(&ids, (size_t)n_prims));

@@ -381,6 +381,8 @@ hipError_t gpu_emit_prims(const GpuRefPass& ref, const int32_t* dev_ids, int32_t
 }
 
 hipError_t gpu_same_objects(const GpuRefPass& ref, const int32_t* dev_slot_ids, int32_t id_stride, int32_t count, int32_t* mismatches, hipStream_t stream) {
+	*mismatches = 0;
+	if (count < 1) return hipSuccess;  // a scene in which nothing can be hit
 	Owned mem;
 	int32_t* bad;
 	RP_TRY(dev_alloc(&mem.ptrs, &bad, 1));

@@ -49,10 +49,18 @@ def check_against_oracle(rt, oracle, r, sc, cam, seed, depth, f32_bound=2e-4):
 
 
 @pytest.mark.parametrize("ref_gpu", [0, 1])
-@pytest.mark.parametrize("scene", SCENES + ["one"])
+@pytest.mark.parametrize("scene", SCENES + ["one", "nothing_to_hit"])
 def test_refit_where_the_objects_are_changes_nothing(rt, scene, ref_gpu):
-    sc = rt.Scene(rt.Scene.generate("simple").objects[:1].copy()) if scene == "one" else rt.Scene.generate(scene)
-    cam = camera_args("simple" if scene == "one" else scene, 160, 90, rt)
+    from raytracer_amd import _native as N
+    if scene == "one":
+        sc = rt.Scene(rt.Scene.generate("simple").objects[:1].copy())
+    elif scene == "nothing_to_hit":      # a cube with a negative half extent: in the reference's tree, never hit
+        sc = rt.Scene(rt.Scene.generate("simple").objects[:1].copy())
+        sc.objects["kind"][0] = N.CUBE
+        sc.objects["extent"][0] = (0.5, 0.5, -0.2)
+    else:
+        sc = rt.Scene.generate(scene)
+    cam = camera_args(scene if scene in SCENES else "simple", 160, 90, rt)
     r = rt.Renderer(sc, rt.Camera(*cam), seed=3, max_depth=10, options={"ref_gpu": ref_gpu})
     r.set_option("count", 1)
     before = words(r)
