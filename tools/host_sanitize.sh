@@ -1,6 +1,6 @@
 #!/bin/bash
 # The host half of librthip (scene factories, reference tree, ranks, gates, surface-area build,
-# quantisation, the layout for the device-side build) under ASan + UBSan.  No GPU needed.
+# quantisation, the layouts for the device-side build, the records of a refit) under ASan + UBSan.  No GPU needed.
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d /tmp/rthip_san_XXXX)
