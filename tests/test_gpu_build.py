@@ -184,3 +184,34 @@ def test_device_reference_pass_equals_host_pass(rt, scene):
             host.refit_scene(new)
     print(f"[device reference pass] {scene}: {a['n_gates']} gate boxes, {a['n_leaves']} reference leaves")
     dev.close(); host.close()
+
+
+@pytest.mark.parametrize("spheres", [0, 1, 3])
+@pytest.mark.parametrize("tree_gpu", [0, 1])
+def test_large_scene_of_cubes_that_cannot_be_hit(rt, oracle, spheres, tree_gpu):
+    """3 000 cubes with a negative half extent (they shape the reference's tree and are in no device
+    tree) and at most three spheres: large enough for the device's reference pass, too few
+    primitives for a device-built tree (or for any tree at all)."""
+    from raytracer_amd import _native as N
+    g = np.random.default_rng(8)
+    n = 3000
+    o = np.zeros(n + spheres, dtype=N.OBJECT_DTYPE)
+    o["kind"][:n], o["material"][:n] = N.CUBE, N.LAMBERTIAN
+    o["center"][:n] = g.uniform(-5, 5, (n, 3))
+    o["extent"][:n] = g.uniform(0.05, 0.3, (n, 3)) * [1.0, -1.0, 1.0]
+    o["albedo"][:] = 0.6
+    o["kind"][n:], o["material"][n:] = N.SPHERE, N.METAL
+    o["center"][n:] = np.array([(0.0, 1.0, 0.0), (1.5, 0.5, 0.5), (-1.0, 0.3, 1.0)])[:spheres]
+    o["extent"][n:, 0] = np.array([1.0, 0.5, 0.3])[:spheres]
+    sc = rt.Scene(o)
+    cam = ((9.0, 4.0, 11.0), (-9.0, -3.5, -11.0), 40.0, 10.0, 0.2, 96, 54)
+    r = rt.Renderer(sc, rt.Camera(*cam), seed=5, precision=rt.F64, max_depth=8, options={"tree_gpu": tree_gpu})
+    assert r.stats()["n_prims"] == spheres
+    r.validate_tree()
+    osc = oracle.OracleScene(sc.objects)
+    desc = oracle.camera_desc(*cam)
+    _, smp, cnt, _ = osc.render(desc, 2, 8, 5, oracle.TIGHT, samples=True)
+    assert np.array_equal(r.render_samples(2), smp) and r.stats()["rays"] == cnt["rays"]
+    r.refit_scene(sc)
+    assert np.array_equal(r.render_samples(2), smp)
+    r.close()
