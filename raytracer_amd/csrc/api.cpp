@@ -878,8 +878,8 @@ int32_t rthip_scene_refit(rthip_ctx* c, const rthip_object* objects, int64_t n) 
 		if (reference_pass_on_device(c->build_opt, n)) {
 			// ranks, gates and the primitive records on the device; the id words of the primitives the
 			// tree holds say which object goes where
-			if (!check_scene_objects(objects, n, &err)) return fail(c, RTHIP_ERR_INVALID, err);
-			const int64_t hittable = count_hittable(objects, n);
+			int64_t hittable = 0;
+			if (!check_scene_objects(objects, n, &err, &hittable)) return fail(c, RTHIP_ERR_INVALID, err);
 			if (hittable != c->n_prims)
 				return fail(c, RTHIP_ERR_INVALID, "refit: " + std::to_string(hittable) + " objects can be hit, the tree holds " + std::to_string(c->n_prims) + " (upload the scene instead)");
 			RefPassHolder h;

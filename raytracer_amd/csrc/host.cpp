@@ -787,15 +787,38 @@ BuildOptions BuildOptions::from_env() {
 }
 
 namespace {
-bool check_objects(const rthip_object* objs, int64_t n, std::string* err) {
+// Checks every object (known kind and material, finite fields) and counts those that can be hit
+// at all (every sphere; cubes without a negative half extent).  Large scenes on eight threads.
+bool check_objects(const rthip_object* objs, int64_t n, std::string* err, int64_t* hittable = nullptr) {
 	if (n <= 0) { *err = "empty scene: BVH::new returns None"; return false; }
 	if (n > kMaxObjects) { *err = "too many objects"; return false; }
-	for (int64_t i = 0; i < n; i++) {
-		const rthip_object& o = objs[i];
-		bool ok = (o.kind == RTHIP_SPHERE || o.kind == RTHIP_CUBE) && o.material >= 0 && o.material <= 2 && std::isfinite(o.param);
-		for (int k = 0; k < 3; k++) ok = ok && std::isfinite(o.center[k]) && std::isfinite(o.albedo[k]) && (o.kind == RTHIP_SPHERE ? std::isfinite(o.extent[0]) : std::isfinite(o.extent[k]));
-		if (!ok) { *err = "object " + std::to_string(i) + " has an invalid kind, material or a non-finite field"; return false; }
+	struct Part { int64_t first_bad = -1, hittable = 0; };
+	const auto scan = [objs](int64_t begin, int64_t end) {
+		Part p;
+		for (int64_t i = begin; i < end; i++) {
+			const rthip_object& o = objs[i];
+			bool ok = (o.kind == RTHIP_SPHERE || o.kind == RTHIP_CUBE) && o.material >= 0 && o.material <= 2 && std::isfinite(o.param);
+			for (int k = 0; k < 3; k++) ok = ok && std::isfinite(o.center[k]) && std::isfinite(o.albedo[k]) && (o.kind == RTHIP_SPHERE ? std::isfinite(o.extent[0]) : std::isfinite(o.extent[k]));
+			if (!ok) { p.first_bad = i; return p; }
+			p.hittable += (o.kind == RTHIP_SPHERE || (o.extent[0] >= 0.0 && o.extent[1] >= 0.0 && o.extent[2] >= 0.0)) ? 1 : 0;
+		}
+		return p;
+	};
+	Part all;
+	if (n >= 65536) {
+		constexpr int kParts = 8;
+		std::vector<std::future<Part>> jobs;
+		for (int k = 0; k < kParts; k++) jobs.push_back(std::async(std::launch::async, scan, n * k / kParts, n * (k + 1) / kParts));
+		for (auto& j : jobs) {
+			const Part p = j.get();
+			if (p.first_bad >= 0 && all.first_bad < 0) all.first_bad = p.first_bad;  // parts are in order: the first one reported is the lowest
+			all.hittable += p.hittable;
+		}
+	} else {
+		all = scan(0, n);
 	}
+	if (all.first_bad >= 0) { *err = "object " + std::to_string(all.first_bad) + " has an invalid kind, material or a non-finite field"; return false; }
+	if (hittable) *hittable = all.hittable;
 	return true;
 }
 // What every build starts with: the input checked, the materials by object id, and the reference's
@@ -1182,14 +1205,7 @@ bool plan_device_scene(const rthip_object* objs, int64_t n, FlatScene* out, std:
 	return true;
 }
 
-bool check_scene_objects(const rthip_object* objs, int64_t n, std::string* err) { return check_objects(objs, n, err); }
-
-int64_t count_hittable(const rthip_object* objs, int64_t n) {
-	int64_t k = 0;
-	for (int64_t i = 0; i < n; i++)
-		k += (objs[i].kind == RTHIP_SPHERE || (objs[i].extent[0] >= 0.0 && objs[i].extent[1] >= 0.0 && objs[i].extent[2] >= 0.0)) ? 1 : 0;
-	return k;
-}
+bool check_scene_objects(const rthip_object* objs, int64_t n, std::string* err, int64_t* hittable) { return check_objects(objs, n, err, hittable); }
 
 uint64_t checksum_flat_scene(const FlatScene& s) {
 	uint64_t h = 1469598103934665603ull;

@@ -94,10 +94,9 @@ bool refit_flat_scene(const rthip_object* objs, int64_t n, const int32_t* slot_i
 // slot_ids receives the object id of every primitive place.  out->gpu.on stays false for scenes of
 // fewer than two leaves (build those on the host).
 bool plan_device_scene(const rthip_object* objs, int64_t n, FlatScene* out, std::vector<int32_t>* slot_ids, std::string* err, const BuildOptions& opt);
-// check_objects only (refit on the device)
-bool check_scene_objects(const rthip_object* objs, int64_t n, std::string* err);
-// Objects that can be hit at all (every sphere; cubes without a negative half extent).
-int64_t count_hittable(const rthip_object* objs, int64_t n);
+// The checks every build starts with (known kinds and materials, finite fields), and the number of
+// objects that can be hit at all (every sphere; cubes without a negative half extent).
+bool check_scene_objects(const rthip_object* objs, int64_t n, std::string* err, int64_t* hittable = nullptr);
 // Checks the invariant every culling decision rests on: each f32 child box (centre and half
 // extent), and each quantised one, contains the f32 bounds of every primitive below it; every
 // primitive that can be hit is in exactly one leaf; the tree is no deeper than reported.

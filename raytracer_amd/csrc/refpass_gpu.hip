@@ -53,6 +53,17 @@ __global__ void ref_boxes_kernel(const rthip_object* objs, int32_t n, double* rl
 	order[i] = i;
 }
 
+// Spheres of a negative radius, numbered in object order (the only objects a box above them may
+// fail to contain: they alone can have gates).
+__global__ void neg_flags_kernel(const rthip_object* objs, int32_t n, uint32_t* flags) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	if (i < n) flags[i] = (objs[i].kind == RTHIP_SPHERE && objs[i].extent[0] < 0.0) ? 1u : 0u;
+}
+__global__ void neg_index_kernel(int32_t n, const uint32_t* flags, const uint32_t* at, int32_t* neg_index) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	if (i < n) neg_index[i] = flags[i] ? (int32_t)at[i] : -1;
+}
+
 // The state of a position: the range [b, e) of the node it belongs to at the current level, and
 // whether that node was a leaf of an earlier level (frozen: nothing moves there any more).
 struct Ranges { uint32_t *b, *e; uint8_t* frozen; };
@@ -285,11 +296,6 @@ hipError_t gpu_reference_pass(const rthip_object* host_objs, int64_t n64, hipStr
 	const size_t nn = (size_t)n;
 	const int levels = ref_tree_levels(n64);  // inner levels; nodes (leaves included) stand on levels 0 .. levels
 	if (levels + 1 > 62) return hipErrorInvalidValue;
-	// spheres of negative radius: the only objects a box above them may fail to contain
-	std::vector<int32_t> neg_index(nn, -1);
-	int32_t n_neg = 0;
-	for (int32_t i = 0; i < n; i++)
-		if (host_objs[i].kind == RTHIP_SPHERE && host_objs[i].extent[0] < 0.0) neg_index[(size_t)i] = n_neg++;
 	const int32_t max_levels = levels + 1;
 
 	Owned keep;   // what the caller receives (moved out at the end)
@@ -302,6 +308,7 @@ hipError_t gpu_reference_pass(const rthip_object* host_objs, int64_t n64, hipStr
 	uint32_t *seg_a, *seg_b, *counts, *firsts;
 	unsigned long long *segbox, *keys_a, *keys_b, *vals_a, *vals_b, *gate_mask;
 	Ranges r;
+	const unsigned grid = (unsigned)((nn + kBlock - 1) / kBlock);
 	RP_TRY(dev_alloc(&mem.ptrs, &rlo, 3 * nn)); RP_TRY(dev_alloc(&mem.ptrs, &rhi, 3 * nn));
 	RP_TRY(dev_alloc(&mem.ptrs, &order_a, nn)); RP_TRY(dev_alloc(&mem.ptrs, &order_b, nn)); RP_TRY(dev_alloc(&mem.ptrs, &d_neg, nn));
 	RP_TRY(dev_alloc(&mem.ptrs, &seg_a, nn)); RP_TRY(dev_alloc(&mem.ptrs, &seg_b, nn));
@@ -309,8 +316,6 @@ hipError_t gpu_reference_pass(const rthip_object* host_objs, int64_t n64, hipStr
 	RP_TRY(dev_alloc(&mem.ptrs, &segbox, 6 * nn));
 	RP_TRY(dev_alloc(&mem.ptrs, &keys_a, nn)); RP_TRY(dev_alloc(&mem.ptrs, &keys_b, nn));
 	RP_TRY(dev_alloc(&mem.ptrs, &vals_a, nn)); RP_TRY(dev_alloc(&mem.ptrs, &vals_b, nn));
-	RP_TRY(dev_alloc(&mem.ptrs, &gate_mask, (size_t)std::max(n_neg, 1)));
-	RP_TRY(dev_alloc(&mem.ptrs, &gate_tmp, (size_t)std::max(n_neg, 1) * (size_t)max_levels * 6));
 	RP_TRY(dev_alloc(&mem.ptrs, &r.b, nn)); RP_TRY(dev_alloc(&mem.ptrs, &r.e, nn)); RP_TRY(dev_alloc(&mem.ptrs, &r.frozen, nn));
 	int seg_bits = 1;
 	while ((1ll << seg_bits) < n64) seg_bits++;
@@ -323,9 +328,23 @@ hipError_t gpu_reference_pass(const rthip_object* host_objs, int64_t n64, hipStr
 	RP_TRY(dev_alloc(&mem.ptrs, &temp, temp_bytes));
 
 	RP_TRY(hipMemcpyAsync(objs, host_objs, nn * sizeof(rthip_object), hipMemcpyHostToDevice, stream));
-	RP_TRY(hipMemcpyAsync(d_neg, neg_index.data(), nn * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+	// the spheres that can have gates, numbered (counts and firsts serve as scratch here)
+	hipLaunchKernelGGL(neg_flags_kernel, dim3(grid), dim3(kBlock), 0, stream, objs, n, counts);
+	RP_TRY(hipGetLastError());
+	{
+		size_t bytes = temp_bytes;
+		RP_TRY(hipcub::DeviceScan::ExclusiveSum(temp, bytes, counts, firsts, n, stream));
+	}
+	hipLaunchKernelGGL(neg_index_kernel, dim3(grid), dim3(kBlock), 0, stream, n, counts, firsts, d_neg);
+	RP_TRY(hipGetLastError());
+	uint32_t neg_last_at = 0, neg_last_flag = 0;
+	RP_TRY(hipMemcpyAsync(&neg_last_at, firsts + (nn - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	RP_TRY(hipMemcpyAsync(&neg_last_flag, counts + (nn - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	RP_TRY(hipStreamSynchronize(stream));
+	const int32_t n_neg = (int32_t)(neg_last_at + neg_last_flag);
+	RP_TRY(dev_alloc(&mem.ptrs, &gate_mask, (size_t)std::max(n_neg, 1)));
+	RP_TRY(dev_alloc(&mem.ptrs, &gate_tmp, (size_t)std::max(n_neg, 1) * (size_t)max_levels * 6));
 	RP_TRY(hipMemsetAsync(gate_mask, 0, (size_t)std::max(n_neg, 1) * sizeof(unsigned long long), stream));
-	const unsigned grid = (unsigned)((nn + kBlock - 1) / kBlock);
 	hipLaunchKernelGGL(ref_boxes_kernel, dim3(grid), dim3(kBlock), 0, stream, objs, n, rlo, rhi, order_a);
 	hipLaunchKernelGGL(ranges_init_kernel, dim3(grid), dim3(kBlock), 0, stream, r, n);
 	RP_TRY(hipGetLastError());

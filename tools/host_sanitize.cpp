@@ -20,7 +20,9 @@ int main() {
 			{
 				FlatScene plan; std::vector<int32_t> slots;
 				if (!plan_device_scene(objs.data(), (int64_t)objs.size(), &plan, &slots, &err, o)) { printf("plan %s: %s\n", nm, err.c_str()); return 1; }
-				if (plan.gpu.on && (int64_t)slots.size() != count_hittable(objs.data(), (int64_t)objs.size())) { printf("plan %s: %zu slots\n", nm, slots.size()); return 1; }
+				int64_t hittable = -1;
+				if (!check_scene_objects(objs.data(), (int64_t)objs.size(), &err, &hittable)) { printf("check %s: %s\n", nm, err.c_str()); return 1; }
+				if (plan.gpu.on && (int64_t)slots.size() != hittable) { printf("plan %s: %zu slots\n", nm, slots.size()); return 1; }
 				std::vector<int32_t> ids;
 				for (const Prim<float>& p : s.prims32) ids.push_back(p.id);
 				FlatScene again;
