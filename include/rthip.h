@@ -129,7 +129,9 @@ int32_t rthip_scene_upload(rthip_ctx* ctx, const rthip_object* objects, int64_t 
  * extent), else RTHIP_ERR_INVALID and the scene on the device stays as it was.  The device tree keeps its shape
  * and its boxes are fitted again on the GPU, bottom up, one launch per level; tie ranks and gates are those
  * of the reference's tree over the objects as they now are, so every result equals that of a fresh
- * upload.  Far-reaching moves leave a tree that is sound but slow to walk: upload then. */
+ * upload.  Far-reaching moves leave a tree that is sound but slow to walk: upload then.
+ * `objects` may point into device memory (of the context's GPU) for both calls; a refit of a scene
+ * of 2 048 objects and more then runs without a copy to or from the host. */
 int32_t rthip_scene_refit(rthip_ctx* ctx, const rthip_object* objects, int64_t n);
 /* Replaces Camera::new (src/camera.rs:25-69).  Changing the image size resets the
  * accumulation buffer; changing only the pose does not (callers reset, as

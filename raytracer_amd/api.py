@@ -210,6 +210,14 @@ class Renderer:
         self._objs = objs
         self.reset_accumulation()
 
+    def refit_device_objects(self, device_ptr, n):
+        """refit_scene for objects that live in device memory: `n` records of the object layout
+        (88 bytes each) at `device_ptr` (a torch tensor's data_ptr(), say).  Scenes of 2 048
+        objects and more are refitted without a copy to or from the host."""
+        self._check(self._lib.rthip_scene_refit(self._ctx, C.c_void_p(int(device_ptr)), int(n)))
+        self._objs = None
+        self.reset_accumulation()
+
     def _raise(self, code):
         msg = self._lib.rthip_last_error(self._ctx)
         raise N.RthipError(code, msg.decode() if msg else "")

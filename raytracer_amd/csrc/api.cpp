@@ -280,6 +280,12 @@ int32_t regate_blob(rthip_ctx* c, size_t n_nodes, size_t n_prims, size_t n_gates
 	b->lds_bytes_mats = align_up(mats_off + mb, 64);
 	return RTHIP_OK;
 }
+// Callers may hand over objects that live in device memory (a simulation on the GPU, a torch tensor).
+bool in_device_memory(const void* p) {
+	hipPointerAttribute_t attr{};
+	if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }  // plain host memory the runtime knows nothing of
+	return attr.type == hipMemoryTypeDevice;
+}
 // Whether ranks, gates and primitive records of a scene of n objects are made on the device (see BuildOptions::ref_gpu).
 bool reference_pass_on_device(const BuildOptions& o, int64_t n) {
 	if (o.tie_reverse) return false;  // the other tie order is the host pass's knob
@@ -738,6 +744,13 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 		if (n == 0) return fail(c, RTHIP_ERR_EMPTY, "empty scene: BVH::new returns None");
 		HIP_TRY(c, hipSetDevice(c->device));
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		std::vector<rthip_object> fetched;  // objects handed over in device memory: a build starts on the host
+		if (in_device_memory(objects)) {
+			if (n > kMaxObjects) return fail(c, RTHIP_ERR_INVALID, "too many objects");
+			fetched.resize((size_t)n);
+			HIP_TRY(c, hipMemcpy(fetched.data(), objects, (size_t)n * sizeof(rthip_object), hipMemcpyDeviceToHost));
+			objects = fetched.data();
+		}
 		FlatScene flat;
 		std::string err;
 		int32_t rc = RTHIP_OK;
@@ -875,11 +888,24 @@ int32_t rthip_scene_refit(rthip_ctx* c, const rthip_object* objects, int64_t n) 
 		int32_t rc = RTHIP_OK;
 		int64_t n_gates = 0;
 		const auto t_start = std::chrono::steady_clock::now();
+		const bool device_objects = in_device_memory(objects);
+		std::vector<rthip_object> fetched;
+		if (device_objects && !reference_pass_on_device(c->build_opt, n)) {  // the host's pass wants them on the host
+			fetched.resize((size_t)n);
+			HIP_TRY(c, hipMemcpy(fetched.data(), objects, (size_t)n * sizeof(rthip_object), hipMemcpyDeviceToHost));
+			objects = fetched.data();
+		}
 		if (reference_pass_on_device(c->build_opt, n)) {
 			// ranks, gates and the primitive records on the device; the id words of the primitives the
 			// tree holds say which object goes where
 			int64_t hittable = 0;
-			if (!check_scene_objects(objects, n, &err, &hittable)) return fail(c, RTHIP_ERR_INVALID, err);
+			if (device_objects) {  // nothing of such a refit touches the host
+				int64_t first_bad = -1;
+				HIP_TRY(c, gpu_check_objects(objects, n, &first_bad, &hittable, c->stream));
+				if (first_bad >= 0) return fail(c, RTHIP_ERR_INVALID, "object " + std::to_string(first_bad) + " has an invalid kind, material or a non-finite field");
+			} else if (!check_scene_objects(objects, n, &err, &hittable)) {
+				return fail(c, RTHIP_ERR_INVALID, err);
+			}
 			if (hittable != c->n_prims)
 				return fail(c, RTHIP_ERR_INVALID, "refit: " + std::to_string(hittable) + " objects can be hit, the tree holds " + std::to_string(c->n_prims) + " (upload the scene instead)");
 			RefPassHolder h;

@@ -64,9 +64,12 @@ struct GpuRefPass {  // device arrays; the holder calls release()
 // leaves: both follow from n alone (src/bvh.rs:52,62: leaves of fewer than six, splits at len / 2).
 int ref_tree_levels(int64_t n);
 int64_t ref_tree_leaves(int64_t n);
-// Copies the objects to the device and computes tie ranks and gates there.  The objects must have
+// The checks of host.cpp's check_scene_objects for objects in device memory: first_bad = the lowest
+// index of an invalid object or -1; hittable = objects that can be hit at all.
+hipError_t gpu_check_objects(const rthip_object* dev_objs, int64_t n, int64_t* first_bad, int64_t* hittable, hipStream_t stream);
+// Copies the objects (from host or device memory) and computes tie ranks and gates on the device.  The objects must have
 // been checked (finite fields, known kinds).  Runs on `stream` and waits for it; about 250 bytes of scratch per object.
-hipError_t gpu_reference_pass(const rthip_object* host_objs, int64_t n, hipStream_t stream, GpuRefPass* out);
+hipError_t gpu_reference_pass(const rthip_object* objs, int64_t n, hipStream_t stream, GpuRefPass* out);
 // The primitive and the material of object (dev_ids[s * id_stride] & id mask) into slot s of the four
 // arrays; the ids may be the id words of those very primitives (stride 8 from &p32[0].id).
 hipError_t gpu_emit_prims(const GpuRefPass& ref, const int32_t* dev_ids, int32_t id_stride, int32_t count, Prim<float>* p32, Prim<double>* p64, Mat<float>* m32, Mat<double>* m64, hipStream_t stream);

@@ -246,6 +246,23 @@ __global__ void same_objects_kernel(const rthip_object* objs, int32_t n, const i
 	if (!ok) atomicAdd(bad, 1);
 }
 
+// The checks every build starts with (host.cpp check_objects), for objects that live on the device:
+// the lowest index of an object with an unknown kind or material or a non-finite field, and the
+// number of objects that can be hit at all.
+__global__ void check_objects_kernel(const rthip_object* objs, int32_t n, int32_t* first_bad, unsigned long long* hittable) {
+	const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+	bool can_hit = false;
+	if (i < n) {
+		const rthip_object& o = objs[i];
+		bool ok = (o.kind == RTHIP_SPHERE || o.kind == RTHIP_CUBE) && o.material >= 0 && o.material <= 2 && isfinite(o.param);
+		for (int k = 0; k < 3; k++) ok = ok && isfinite(o.center[k]) && isfinite(o.albedo[k]) && (o.kind == RTHIP_SPHERE ? isfinite(o.extent[0]) : isfinite(o.extent[k]));
+		if (!ok) atomicMin(first_bad, i);
+		can_hit = ok && (o.kind == RTHIP_SPHERE || (o.extent[0] >= 0.0 && o.extent[1] >= 0.0 && o.extent[2] >= 0.0));
+	}
+	const unsigned long long votes = __ballot(can_hit);
+	if ((threadIdx.x & 63) == 0 && votes) atomicAdd(hittable, (unsigned long long)__popcll(votes));
+}
+
 #define RP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
 template <typename T> hipError_t dev_alloc(std::vector<void*>* owned, T** out, size_t n) {
@@ -327,7 +344,7 @@ hipError_t gpu_reference_pass(const rthip_object* host_objs, int64_t n64, hipStr
 	char* temp;
 	RP_TRY(dev_alloc(&mem.ptrs, &temp, temp_bytes));
 
-	RP_TRY(hipMemcpyAsync(objs, host_objs, nn * sizeof(rthip_object), hipMemcpyHostToDevice, stream));
+	RP_TRY(hipMemcpyAsync(objs, host_objs, nn * sizeof(rthip_object), hipMemcpyDefault, stream));  // from the host, or from the caller's device memory
 	// the spheres that can have gates, numbered (counts and firsts serve as scratch here)
 	hipLaunchKernelGGL(neg_flags_kernel, dim3(grid), dim3(kBlock), 0, stream, objs, n, counts);
 	RP_TRY(hipGetLastError());
@@ -389,6 +406,25 @@ hipError_t gpu_reference_pass(const rthip_object* host_objs, int64_t n64, hipStr
 	out->objs = objs; out->rank = rank; out->gate_first = gate_first; out->gate_count = gate_count;
 	out->gates64 = g64; out->gates32 = g32; out->n_gates = n_gates; out->n = n;
 	keep.ptrs.clear();
+	return hipSuccess;
+}
+
+hipError_t gpu_check_objects(const rthip_object* dev_objs, int64_t n, int64_t* first_bad, int64_t* hittable, hipStream_t stream) {
+	if (n < 1 || n > kMaxObjects) return hipErrorInvalidValue;
+	Owned mem;
+	unsigned long long* words;  // [0] hittable, [1] first bad index (as int32 in its low half)
+	RP_TRY(dev_alloc(&mem.ptrs, &words, 2));
+	const unsigned long long init[2] = {0ull, 0x7fffffffull};
+	RP_TRY(hipMemcpyAsync(words, init, sizeof(init), hipMemcpyHostToDevice, stream));
+	hipLaunchKernelGGL(check_objects_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, dev_objs, (int32_t)n,
+	                   reinterpret_cast<int32_t*>(words + 1), words);
+	RP_TRY(hipGetLastError());
+	unsigned long long out[2];
+	RP_TRY(hipMemcpyAsync(out, words, sizeof(out), hipMemcpyDeviceToHost, stream));
+	RP_TRY(hipStreamSynchronize(stream));
+	const int32_t bad = (int32_t)(uint32_t)out[1];
+	*first_bad = bad == 0x7fffffff ? -1 : bad;
+	*hittable = (int64_t)out[0];
 	return hipSuccess;
 }
 

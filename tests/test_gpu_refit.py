@@ -161,3 +161,43 @@ def test_refit_turns_down_other_objects(rt, ref_gpu):
     assert lib.rthip_scene_refit(ctx, objs.ctypes.data, len(objs)) == N.ERR_STATE
     assert lib.rthip_scene_refit(None, objs.ctypes.data, len(objs)) == N.ERR_INVALID
     lib.rthip_destroy(ctx)
+
+
+@pytest.mark.parametrize("scene", ["default", "synthetic:30000"])
+def test_refit_and_upload_from_device_memory(rt, scene):
+    """Objects handed over in device memory (a torch tensor): the same images as from host memory,
+    for a scene the device's pass handles without touching the host and for one small enough to go
+    through the host's pass; invalid objects are found on the device too."""
+    import torch
+    from raytracer_amd import _native as N
+    sc = rt.Scene.generate(scene, 0x5EED0001)
+    cam = camera_args("default", 160, 90, rt) if scene == "default" else ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0, 160, 90)
+    new = moved(rt, sc, 3, 0.2)
+
+    def on_device(objs):
+        raw = np.frombuffer(np.ascontiguousarray(objs, dtype=N.OBJECT_DTYPE).tobytes(), dtype=np.uint8)
+        return torch.from_numpy(raw.copy()).cuda()
+
+    host = rt.Renderer(sc, rt.Camera(*cam), seed=4, max_depth=8)
+    host.refit_scene(new)
+    want = words(host)
+    dev = rt.Renderer(sc, rt.Camera(*cam), seed=4, max_depth=8)
+    t = on_device(new.objects)
+    dev.refit_device_objects(t.data_ptr(), len(new))
+    dev.validate_tree()
+    assert np.array_equal(words(dev), want)
+    # an upload from device memory
+    lib = N.lib()
+    N.check(lib.rthip_scene_upload(dev._ctx, C.c_void_p(t.data_ptr()), len(new)), dev._ctx)
+    fresh = rt.Renderer(new, rt.Camera(*cam), seed=4, max_depth=8)
+    assert np.array_equal(words(dev), words(fresh))
+    # a NaN among the objects on the device
+    bad = new.objects.copy()
+    bad["center"][len(bad) // 2, 1] = np.nan
+    tb = on_device(bad)
+    before = words(dev)
+    with pytest.raises(N.RthipError) as e:
+        dev.refit_device_objects(tb.data_ptr(), len(bad))
+    assert e.value.code == N.ERR_INVALID and str(len(bad) // 2) in str(e.value)
+    assert np.array_equal(words(dev), before)
+    host.close(); dev.close(); fresh.close()
