@@ -176,7 +176,7 @@ template <typename Real> void fill_camera(const CameraFields& f, CameraT<Real>* 
 template <typename Real>
 int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const std::vector<Prim<Real>>& prims,
                     const std::vector<Mat<Real>>& mats, const std::vector<Gate<Real>>& gates, SceneBlob* b,
-                    const std::vector<QNode>* qnodes = nullptr, const QFrame* qframe = nullptr) {
+                    const std::vector<QNode>* qnodes = nullptr, const QFrame* qframe = nullptr, bool records_follow = false) {
 	uint64_t nb = nodes.size() * sizeof(Node<Real>), pb = prims.size() * sizeof(Prim<Real>), mb = mats.size() * sizeof(Mat<Real>);
 	uint64_t gb = gates.size() * sizeof(Gate<Real>);
 	uint64_t prims_off = align_up(nb, 64), gates_off = align_up(prims_off + pb, 64), mats_off = align_up(gates_off + gb, 64);
@@ -185,16 +185,19 @@ int32_t upload_blob(rthip_ctx* c, const std::vector<Node<Real>>& nodes, const st
 	uint64_t total = align_up(q_off + qb, 64);
 	if (total > 0xFFFFFFF0ull) return fail(c, RTHIP_ERR_LIMIT, "scene larger than 4 GiB");
 	if (b->dev) { HIP_TRY(c, hipFree(b->dev)); b->dev = nullptr; }
-	std::vector<char> host((size_t)total, 0);
-	std::memcpy(host.data(), nodes.data(), (size_t)nb);
-	std::memcpy(host.data() + prims_off, prims.data(), (size_t)pb);
-	std::memcpy(host.data() + mats_off, mats.data(), (size_t)mb);
-	if (gb) std::memcpy(host.data() + gates_off, gates.data(), (size_t)gb);
-	if (qb) std::memcpy(host.data() + q_off, qnodes->data(), (size_t)qb);
 	b->qnodes_off = qb ? (uint32_t)q_off : 0u;
 	if (qb) b->qframe = *qframe;
 	HIP_TRY(c, hipMalloc(&b->dev, (size_t)total));
-	HIP_TRY(c, hipMemcpy(b->dev, host.data(), (size_t)total, hipMemcpyHostToDevice));
+	// each array straight to its place (a staging copy of a million-object scene is a quarter of a gigabyte);
+	// the padding between the arrays is zeroed with the blob
+	HIP_TRY(c, hipMemset(b->dev, 0, (size_t)total));
+	if (nb) HIP_TRY(c, hipMemcpy(b->dev, nodes.data(), (size_t)nb, hipMemcpyHostToDevice));
+	if (!records_follow) {  // (else the device writes primitives, materials and gates itself: only their room is needed)
+		if (pb) HIP_TRY(c, hipMemcpy(b->dev + prims_off, prims.data(), (size_t)pb, hipMemcpyHostToDevice));
+		if (mb) HIP_TRY(c, hipMemcpy(b->dev + mats_off, mats.data(), (size_t)mb, hipMemcpyHostToDevice));
+		if (gb) HIP_TRY(c, hipMemcpy(b->dev + gates_off, gates.data(), (size_t)gb, hipMemcpyHostToDevice));
+	}
+	if (qb) HIP_TRY(c, hipMemcpy(b->dev + q_off, qnodes->data(), (size_t)qb, hipMemcpyHostToDevice));
 	b->prims_off = (uint32_t)prims_off; b->mats_off = (uint32_t)mats_off; b->gates_off = (uint32_t)gates_off; b->bytes = (uint32_t)total;
 	b->lds_bytes = (uint32_t)mats_off;
 	b->lds_bytes_mats = align_up(mats_off + mb, 64);
@@ -827,9 +830,9 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 				flat.ref_depth = std::max(1, ref_tree_levels(n));
 			}
 			c->has_scene = false;
-			rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32, &flat.qnodes, &flat.qframe);
+			rc = upload_blob<float>(c, flat.nodes32, flat.prims32, flat.mats32, flat.gates32, &c->blob32, &flat.qnodes, &flat.qframe, ranks_on_device);
 			if (rc != RTHIP_OK) return rc;
-			rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64);
+			rc = upload_blob<double>(c, flat.nodes64, flat.prims64, flat.mats64, flat.gates64, &c->blob64, nullptr, nullptr, ranks_on_device);
 			if (rc != RTHIP_OK) return rc;
 			n_prims = (int64_t)flat.prims32.size(); n_gates = (int64_t)flat.gates32.size();
 			if (ranks_on_device) {
@@ -837,11 +840,19 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 					HIP_TRY(c, hipMemcpy(c->blob32.dev + c->blob32.gates_off, h.ref.gates32, (size_t)n_gates * sizeof(Gate<float>), hipMemcpyDeviceToDevice));
 					HIP_TRY(c, hipMemcpy(c->blob64.dev + c->blob64.gates_off, h.ref.gates64, (size_t)n_gates * sizeof(Gate<double>), hipMemcpyDeviceToDevice));
 				}
-				const int32_t* id_words = reinterpret_cast<const int32_t*>(c->blob32.dev + c->blob32.prims_off + offsetof(Prim<float>, id));
-				HIP_TRY(c, gpu_emit_prims(h.ref, id_words, (int32_t)(sizeof(Prim<float>) / sizeof(int32_t)), (int32_t)n_prims,
-				                          reinterpret_cast<Prim<float>*>(c->blob32.dev + c->blob32.prims_off), reinterpret_cast<Prim<double>*>(c->blob64.dev + c->blob64.prims_off),
-				                          reinterpret_cast<Mat<float>*>(c->blob32.dev + c->blob32.mats_off), reinterpret_cast<Mat<double>*>(c->blob64.dev + c->blob64.mats_off), c->stream));
-				HIP_TRY(c, hipStreamSynchronize(c->stream));
+				// which object the host's tree holds in which place: 4 bytes per primitive go up instead of its 144 bytes of records
+				std::vector<int32_t> slot_ids((size_t)n_prims);
+				for (size_t i = 0; i < slot_ids.size(); i++) slot_ids[i] = flat.prims32[i].id;
+				int32_t* d_ids = nullptr;
+				HIP_TRY(c, hipMalloc(&d_ids, std::max<size_t>(slot_ids.size(), 1) * sizeof(int32_t)));
+				hipError_t e = hipMemcpy(d_ids, slot_ids.data(), slot_ids.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+				if (e == hipSuccess)
+					e = gpu_emit_prims(h.ref, d_ids, 1, (int32_t)n_prims, reinterpret_cast<Prim<float>*>(c->blob32.dev + c->blob32.prims_off),
+					                   reinterpret_cast<Prim<double>*>(c->blob64.dev + c->blob64.prims_off), reinterpret_cast<Mat<float>*>(c->blob32.dev + c->blob32.mats_off),
+					                   reinterpret_cast<Mat<double>*>(c->blob64.dev + c->blob64.mats_off), c->stream);
+				if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+				(void)hipFree(d_ids);
+				HIP_TRY(c, e);
 			}
 		}
 		if (flat.gpu.on) {

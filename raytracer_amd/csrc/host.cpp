@@ -742,20 +742,19 @@ struct Builder {
 		int32_t me = new_node();
 		Sub l, r;
 		if (threads_on && n >= 32768 && depth < 5) {
-			// the halves are disjoint slices of items[]: build them side by side, each into a list of its own
-			Sink left_part, right_part;
-			auto left = std::async(std::launch::async, [&, begin, mid, depth] {
-				local_sink() = &left_part;
-				Sub sub = sah_build(begin, mid, depth + 1);
+			// the halves are disjoint slices of items[]: build them side by side.  The left one goes straight
+			// into this thread's list, where it follows the node as in a single-threaded build; the right
+			// one into a list of its own that is appended when both are done (so an element is copied once per
+			// right turn above it, not once per level).
+			Sink right_part;
+			auto right = std::async(std::launch::async, [&, mid, end, depth] {
+				local_sink() = &right_part;
+				Sub sub = sah_build(mid, end, depth + 1);
 				local_sink() = nullptr;
 				return sub;
 			});
-			Sink* mine = local_sink();
-			local_sink() = &right_part;
-			r = sah_build(mid, end, depth + 1);
-			local_sink() = mine;
-			l = left.get();
-			l = splice(left_part, l);
+			l = sah_build(begin, mid, depth + 1);
+			r = right.get();
 			r = splice(right_part, r);
 		} else {
 			l = sah_build(begin, mid, depth + 1);
