@@ -90,6 +90,11 @@ typedef struct rthip_stats {
 	int32_t n_nodes, n_leaves, n_prims, tree_depth; /* of the uploaded scene */
 	int32_t scene_in_lds;   /* 1 when the last render kept the scene in LDS */
 	int32_t n_gates;        /* gate boxes of the uploaded scene (inverted spheres parted from their outer shell) */
+	/* shape of the last render call's megakernel launch (0 for the wavefront variant) */
+	int32_t launch_threads;    /* threads per workgroup */
+	int32_t launch_grid;       /* workgroups (all resident: the grid is persistent) */
+	int32_t launch_lds_bytes;  /* dynamic LDS per workgroup */
+	int32_t waves_per_cu;      /* resident waves per CU the launch was planned for */
 } rthip_stats;
 
 typedef struct rthip_ctx rthip_ctx;

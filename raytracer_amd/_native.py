@@ -39,7 +39,8 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("box_tests", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("cube_tests", C.c_uint64), ("kernel_ms", C.c_double), ("n_nodes", C.c_int32), ("n_leaves", C.c_int32),
-                ("n_prims", C.c_int32), ("tree_depth", C.c_int32), ("scene_in_lds", C.c_int32), ("n_gates", C.c_int32)]
+                ("n_prims", C.c_int32), ("tree_depth", C.c_int32), ("scene_in_lds", C.c_int32), ("n_gates", C.c_int32),
+                ("launch_threads", C.c_int32), ("launch_grid", C.c_int32), ("launch_lds_bytes", C.c_int32), ("waves_per_cu", C.c_int32)]
 
 
 # Every symbol include/rthip.h declares: name -> (restype, argtypes)

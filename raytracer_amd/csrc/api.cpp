@@ -54,6 +54,11 @@ struct Tuning {
 	int scene_lds = -1;       // RTHIP_SCENE_LDS: -1 = by size, 0 = never, 1 = whenever it fits 100 KB
 	int qnodes = 1;           // RTHIP_QNODES: traverse the quantised nodes of large f32 scenes
 	int mats_lds = 1;         // RTHIP_MATS_LDS: keep the materials in LDS too when that costs no resident wave
+	int stack_mem = 0;        // RTHIP_STACK_MEM: scenes in LDS keep the lanes' traversal stacks in global memory (f32 megakernel)
+	int xchg = 0;             // RTHIP_XCHG: exchange queues (rays regrouped by shading arm), f32 megakernel with the scene in LDS
+	int xchg_cap = 128;       // RTHIP_XCHG_CAP: records per queue (rounded down to a power of two, 64 at least)
+	int xchg_pop_min = 16;    // RTHIP_XCHG_POP_MIN
+	int xchg_push_max = 64;   // RTHIP_XCHG_PUSH_MAX
 	int acc_lds = -1;         // RTHIP_ACC_LDS: per-wave accumulation tiles in LDS: -1 = scenes with nothing below the root, 0 = never, 1 = wherever they fit
 	int threads = 0;          // RTHIP_THREADS: force the workgroup size (256, 512, 1024), 0 = most resident waves
 	int blocks_per_cu = 0;    // RTHIP_BLOCKS_PER_CU: cap on resident workgroups per CU, 0 = none
@@ -72,6 +77,11 @@ struct Tuning {
 		t.qnodes = env_int("RTHIP_QNODES", t.qnodes);
 		t.mats_lds = env_int("RTHIP_MATS_LDS", t.mats_lds);
 		t.acc_lds = env_int("RTHIP_ACC_LDS", t.acc_lds);
+		t.stack_mem = env_int("RTHIP_STACK_MEM", t.stack_mem);
+		t.xchg = env_int("RTHIP_XCHG", t.xchg);
+		t.xchg_cap = env_int("RTHIP_XCHG_CAP", t.xchg_cap);
+		t.xchg_pop_min = env_int("RTHIP_XCHG_POP_MIN", t.xchg_pop_min);
+		t.xchg_push_max = env_int("RTHIP_XCHG_PUSH_MAX", t.xchg_push_max);
 		t.threads = env_int("RTHIP_THREADS", t.threads);
 		t.blocks_per_cu = env_int("RTHIP_BLOCKS_PER_CU", t.blocks_per_cu);
 		t.grid_reserve = env_int("RTHIP_GRID_RESERVE", t.grid_reserve);
@@ -109,6 +119,8 @@ struct rthip_ctx {
 	unsigned long long* accum = nullptr;  // active buffer (own or caller's)
 	uint64_t accum_words = 0;
 
+	char* stack_mem = nullptr;  // traversal stacks of launches that keep them in global memory: tree depth x resident threads words
+	size_t stack_mem_bytes = 0;
 	char* d_control = nullptr;  // 1024 bytes: statistics words from +8, work-queue counters from +512 (one per 64-byte line)
 	char* static_control = nullptr;  // the same block inside this device's static scratch array (rthip_render_accumulate_noalloc)
 	char* last_control = nullptr;    // the block the last launch used: where its statistics are
@@ -125,6 +137,7 @@ struct rthip_ctx {
 	rthip_stats stats{};
 	bool launch_pending = false;
 	bool last_in_lds = false;
+	int last_threads = 0, last_grid = 0, last_lds_bytes = 0, last_waves_per_cu = 0;  // shape of the last megakernel launch
 	ncclComm_t comm = nullptr;  // this context's rank in a communicator of GPUs (rthip_comm_init)
 	int comm_rank = -1, comm_world = 0;
 	// Reduces run on a stream of their own, so that the next frame's tracing (into another buffer)
@@ -308,6 +321,8 @@ struct Plan {
 	LaunchCfg cfg;
 	uint32_t chunk, n_chunks, n_items;
 	int32_t threshold;
+	int waves_per_cu;             // resident waves per CU the launch is planned for
+	uint32_t xchg_off, xchg_cap;  // exchange queues: where they start in the workgroup's LDS, records per queue
 };
 
 int32_t validate(rthip_ctx* c, const rthip_render_params* p) {
@@ -325,13 +340,13 @@ int32_t validate(rthip_ctx* c, const rthip_render_params* p) {
 }
 
 // Resident workgroups per CU, asked of the runtime once per kernel variant and LDS size.
-int32_t blocks_per_cu(rthip_ctx* c, bool f64, bool wavefront, int threads, int lds_mode, bool quantised, size_t lds, int* out, bool acc_lds = false) {
-	const auto key = std::make_tuple(f64, wavefront, threads, lds_mode + (acc_lds ? 8 : 0), quantised, lds);
+int32_t blocks_per_cu(rthip_ctx* c, bool f64, bool wavefront, int threads, int lds_mode, bool quantised, size_t lds, int* out, bool acc_lds = false, bool stack_mem = false, bool xchg = false) {
+	const auto key = std::make_tuple(f64, wavefront, threads, lds_mode + (acc_lds ? 8 : 0) + (stack_mem ? 16 : 0) + (xchg ? 32 : 0), quantised, lds);
 	auto it = c->occupancy.find(key);
 	if (it != c->occupancy.end()) { *out = it->second; return RTHIP_OK; }
 	int b = 0;
 	if (wavefront) HIP_TRY(c, f64 ? wf_extend_blocks_per_cu_f64(threads, lds_mode != 0, lds, &b) : wf_extend_blocks_per_cu_f32(threads, lds_mode != 0, lds, &b));
-	else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, lds_mode, lds, &b) : render_blocks_per_cu_f32(threads, lds_mode, lds, &b, quantised, acc_lds));
+	else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, lds_mode, lds, &b) : render_blocks_per_cu_f32(threads, lds_mode, lds, &b, quantised, acc_lds, stack_mem, xchg));
 	c->occupancy[key] = b;
 	*out = b;
 	return RTHIP_OK;
@@ -356,6 +371,17 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// and tail: small workgroups start sooner and finish closer together, which is worth more there than
 	// resident waves (0.38 ms against 0.46 ms for that frame).
 	const bool short_launch = in_lds && !wavefront && my_tiles * kTilePixels * (uint64_t)p->spp_count < 512ull * 24 * (uint64_t)c->num_cu;
+	// Stacks in global memory: f32 megakernel with the scene in LDS (what the freed LDS is for is decided below).
+	const bool stack_mem = tune.stack_mem > 0 && in_lds && !f64 && !wavefront;
+	plan->cfg.stack_mem = stack_mem;
+	// Exchange queues: the same launches, long ones only (the queues pay once they have filled, and a
+	// launch's last rays leave them one wave at a time).
+	uint32_t xcap = 64;
+	while (xcap * 2 <= (uint32_t)std::max(64, std::min(4096, tune.xchg_cap))) xcap *= 2;
+	const bool xchg = tune.xchg > 0 && in_lds && !f64 && !wavefront && !short_launch;
+	plan->cfg.xchg = xchg;
+	plan->xchg_cap = xchg ? xcap : 0;
+	plan->xchg_off = 0;
 	int best_waves = -1, bpc = 0;
 	for (int lds_mode : {2, 1, 0}) {
 		if ((lds_mode != 0) != in_lds) continue;
@@ -365,13 +391,16 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 			if (short_launch && !forced && threads != 256) continue;
 			if (threads == 1024 && (wavefront || forced != 1024 || lds_mode == 2)) continue;  // 32 waves per CU at 64 VGPRs measured no faster than 24 at 80: on request only
 			if (threads == 768 && lds_mode != 2) continue;  // two workgroups of twelve waves: only built for the variant that needs the room
-			size_t lds = (size_t)c->tree_depth * threads * 4 + (lds_mode == 2 ? blob.lds_bytes_mats : lds_mode == 1 ? blob.lds_bytes : 0);
+			size_t lds = (stack_mem ? 0 : (size_t)c->tree_depth * threads * 4) + (lds_mode == 2 ? blob.lds_bytes_mats : lds_mode == 1 ? blob.lds_bytes : 0);
+			const size_t xoff = align_up(lds, 64);
+			if (xchg) lds = xoff + xchg_bytes(xcap);
 			int b = 0;
-			int32_t rc = blocks_per_cu(c, f64, wavefront, threads, lds_mode, plan->cfg.quantised, lds, &b);
+			int32_t rc = blocks_per_cu(c, f64, wavefront, threads, lds_mode, plan->cfg.quantised, lds, &b, false, stack_mem, xchg);
 			if (rc != RTHIP_OK) return rc;
 			if (b * threads / 64 > best_waves) {
 				best_waves = b * threads / 64; bpc = b;
 				plan->cfg.threads = threads; plan->cfg.dyn_lds = lds; plan->cfg.lds_mode = lds_mode;
+				plan->xchg_off = (uint32_t)xoff;
 			}
 		}
 	}
@@ -385,7 +414,7 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	plan->cfg.acc_lds = false;
 	plan->cfg.acc_tile_off = 0;
 	const bool acc_wanted = tune.acc_lds > 0 || (tune.acc_lds < 0 && c->n_nodes <= 1);
-	if (acc_wanted && !f64 && !wavefront && !count && plan->cfg.lds_mode == 2 && p->spp_count >= 8) {
+	if (acc_wanted && !f64 && !wavefront && !count && !stack_mem && !xchg && plan->cfg.lds_mode == 2 && p->spp_count >= 8) {
 		for (int threads : {256, 512}) {
 			if (forced && threads != forced) continue;
 			const size_t base = (size_t)c->tree_depth * threads * 4 + blob.lds_bytes_mats;
@@ -401,6 +430,7 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	}
 	const int cap = tune.blocks_per_cu;
 	if (cap > 0) bpc = std::min(bpc, cap);
+	plan->waves_per_cu = bpc * plan->cfg.threads / 64;
 	// Samples of a tile per work item.  Small items balance short launches (the tail is one item per
 	// wave); long launches want fewer, larger items (millions of items contend on the queue counters
 	// and scatter a tile's accumulation lines).  Measured optimum: 4 up to ~128 spp, 8-16 beyond.
@@ -468,6 +498,20 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.accum = accum; a.samples_out = samples_out;
 	a.queue = reinterpret_cast<uint32_t*>(control + 512);
 	a.stats = reinterpret_cast<unsigned long long*>(control + 8);
+	a.xchg_off = plan.xchg_off; a.xchg_cap = plan.xchg_cap;
+	a.xchg_pop_min = std::max(1, std::min(64, c->tune.xchg_pop_min));
+	a.xchg_push_max = std::max(0, std::min(64, c->tune.xchg_push_max));
+	if (plan.cfg.stack_mem) {
+		const size_t need = (size_t)std::max(1, c->tree_depth) * (size_t)plan.cfg.grid * (size_t)plan.cfg.threads * 4;
+		if (need > 0xFFFFFFFFull) return fail(c, RTHIP_ERR_LIMIT, "traversal stacks in global memory exceed 4 GiB");
+		if (c->stack_mem_bytes < need) {
+			HIP_TRY(c, hipStreamSynchronize(c->stream));  // an earlier launch may still be using the old array
+			if (c->stack_mem) { HIP_TRY(c, hipFree(c->stack_mem)); c->stack_mem = nullptr; c->stack_mem_bytes = 0; }
+			HIP_TRY(c, hipMalloc(&c->stack_mem, need));
+			c->stack_mem_bytes = need;
+		}
+		a.stack_mem = c->stack_mem;
+	}
 	HIP_TRY(c, hipMemsetAsync(control, 0, kControlBytes, c->stream));
 	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
 	if (plan.n_items > 0 && p->spp_count > 0) HIP_TRY(c, launch_render(a, plan.cfg, c->stream));
@@ -475,6 +519,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	c->launch_pending = true;
 	c->last_control = control;
 	c->last_in_lds = plan.cfg.scene_in_lds;
+	c->last_threads = plan.cfg.threads; c->last_grid = plan.cfg.grid; c->last_lds_bytes = (int)plan.cfg.dyn_lds; c->last_waves_per_cu = plan.waves_per_cu;
 	return RTHIP_OK;
 }
 
@@ -551,6 +596,7 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 	c->launch_pending = true;
 	c->last_control = c->d_control;
 	c->last_in_lds = plan.cfg.scene_in_lds;
+	c->last_threads = c->last_grid = c->last_lds_bytes = c->last_waves_per_cu = 0;
 	return RTHIP_OK;
 }
 
@@ -560,13 +606,13 @@ int32_t collect_stats(rthip_ctx* c) {
 	unsigned long long s[5 + 2 * kRegCount + kPhCount];
 	HIP_TRY(c, hipMemcpy(s, (c->last_control ? c->last_control : c->d_control) + 8, sizeof(s), hipMemcpyDeviceToHost));
 	if (!c->tune.region_dump.empty() && c->tune.count) {  // instrumented runs: lane utilisation per code region
-		static const char* names[kRegCount] = {"inner", "sphere", "cube", "leaf", "shade", "sky", "lambert", "metal", "glass", "start", "trav_round"};
+		static const char* names[kRegCount] = {"inner", "sphere", "cube", "leaf", "shade", "sky", "lambert", "metal", "glass", "start", "trav_round", "xchg_push", "xchg_pop", "xchg_full", "xchg_spin"};
 		if (FILE* f = std::fopen(c->tune.region_dump.c_str(), "a")) {
 			for (int k = 0; k < kRegCount; k++)
 				std::fprintf(f, "%s lane_iters %llu wave_iters %llu util %.3f\n", names[k], s[5 + k], s[5 + kRegCount + k],
 				             s[5 + kRegCount + k] ? (double)s[5 + k] / (64.0 * (double)s[5 + kRegCount + k]) : 0.0);
 			// wave clock ticks (s_memtime) per phase of the main loop, summed over the waves, and their share of the waves' lifetime
-			static const char* phases[kPhCount] = {"shade", "regen", "fresh", "inner", "leaf", "total"};
+			static const char* phases[kPhCount] = {"shade", "regen", "fresh", "inner", "leaf", "xchg", "total"};
 			for (int k = 0; k < kPhCount; k++)
 				std::fprintf(f, "phase %s ticks %llu share %.3f\n", phases[k], s[5 + 2 * kRegCount + k],
 				             s[5 + 2 * kRegCount + kPhTotal] ? (double)s[5 + 2 * kRegCount + k] / (double)s[5 + 2 * kRegCount + kPhTotal] : 0.0);
@@ -578,6 +624,8 @@ int32_t collect_stats(rthip_ctx* c) {
 	c->stats.paths = s[0]; c->stats.rays = s[1]; c->stats.box_tests = s[2]; c->stats.sphere_tests = s[3]; c->stats.cube_tests = s[4];
 	c->stats.kernel_ms = ms;
 	c->stats.scene_in_lds = c->last_in_lds ? 1 : 0;
+	c->stats.launch_threads = c->last_threads; c->stats.launch_grid = c->last_grid;
+	c->stats.launch_lds_bytes = c->last_lds_bytes; c->stats.waves_per_cu = c->last_waves_per_cu;
 	c->launch_pending = false;
 	return RTHIP_OK;
 }
@@ -671,6 +719,7 @@ void rthip_destroy(rthip_ctx* c) {
 		if (c->blob64.dev) (void)hipFree(c->blob64.dev);
 		if (c->own_accum) (void)hipFree(c->own_accum);
 		if (c->d_control) (void)hipFree(c->d_control);
+		if (c->stack_mem) (void)hipFree(c->stack_mem);
 		if (c->wf_mem) (void)hipFree(c->wf_mem);
 		if (c->readback) (void)hipFree(c->readback);
 		if (c->wf_counters) (void)hipFree(c->wf_counters);
@@ -703,7 +752,8 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 	if (!c) return RTHIP_ERR_INVALID;
 	return guarded(c, [&]() -> int32_t {
 		if (!name) return fail(c, RTHIP_ERR_INVALID, "option name is NULL");
-		if (!(value == value)) return fail(c, RTHIP_ERR_INVALID, "option value is NaN");
+		// (int)value of a NaN, an infinity or anything beyond the int range is undefined
+		if (!(value == value) || !(value >= -2147483648.0 && value <= 2147483647.0)) return fail(c, RTHIP_ERR_INVALID, "option value is not a number in the int range");
 		const std::string k(name);
 		const int iv = (int)value;
 		Tuning& t = c->tune;
@@ -712,6 +762,11 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		else if (k == "qnodes") t.qnodes = iv;
 		else if (k == "mats_lds") t.mats_lds = iv;
 		else if (k == "acc_lds") t.acc_lds = iv;
+		else if (k == "stack_mem") t.stack_mem = iv;
+		else if (k == "xchg") t.xchg = iv;
+		else if (k == "xchg_cap") t.xchg_cap = iv;
+		else if (k == "xchg_pop_min") t.xchg_pop_min = iv;
+		else if (k == "xchg_push_max") t.xchg_push_max = iv;
 		else if (k == "threads") t.threads = iv;
 		else if (k == "blocks_per_cu") t.blocks_per_cu = iv;
 		else if (k == "grid_reserve") t.grid_reserve = iv;

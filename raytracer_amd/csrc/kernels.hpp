@@ -75,6 +75,10 @@ struct RenderArgs {
 	Real* samples_out;            // optional [spp_count][H][W][3]
 	uint32_t* queue;              // kQueues work-item counters, one per 64-byte line, zeroed before the launch
 	unsigned long long* stats;    // [0] paths [1] rays [2] box tests [3] sphere tests [4] cube tests, then region counters
+	char* stack_mem;              // kStackMem: the lanes' traversal stacks, stack_entries x (grid x threads) words
+	uint32_t xchg_off, xchg_cap;  // kXchg: byte offset in LDS of the workgroup's exchange queues, and records per queue (a power of two)
+	int32_t xchg_pop_min;         // kXchg: take rays out of a queue only this many at a time (or when the wave has nothing else to do)
+	int32_t xchg_push_max;        // kXchg: an arm hands its rays over only when it holds at most this many lanes of the wave
 };
 
 template <typename Real>
@@ -452,22 +456,43 @@ RT_FN bool hit_box_reference(const Real* b, const TravRay<Real>& r) {
 // equal t (src/scene.rs:105) and the right child among equal t (src/bvh.rs:98-104); `rank`
 // encodes that order so the result does not depend on the visiting order.
 // ---------------------------------------------------------------------------------------
+// Where the per-lane stacks live.  A lane's stack pointer (Trav::sp) is kept in the unit its
+// stack addresses with, so that a push or a pop is one add and one memory operation.
+template <int kThreads> struct StackLds {  // LDS, [entry][thread]: conflict-free
+	int* col;                              // this lane's column
+	__device__ __forceinline__ int32_t bottom() const { return 0; }
+	__device__ __forceinline__ void push(int32_t& sp, int32_t v) const { col[sp] = v; sp += kThreads; }
+	__device__ __forceinline__ int32_t pop(int32_t& sp) const { sp -= kThreads; return col[sp]; }
+};
+// Global memory, [entry][every thread of the grid]: the lanes of a wave push to one 256-byte line,
+// the array (tree depth x resident threads x 4 bytes: 16 MB for a depth of ten) stays in L2, and
+// the vector-memory pipe that carries it is idle while the scene is read from LDS.  A lane reads
+// back only what it wrote itself (program order), so no fence is involved.
+struct StackMem {
+	char* base;        // wave-uniform
+	uint32_t first;    // byte offset of this lane's entry 0
+	uint32_t stride;   // bytes from one entry to the next
+	__device__ __forceinline__ int32_t bottom() const { return (int32_t)first; }
+	__device__ __forceinline__ void push(int32_t& sp, int32_t v) const { *reinterpret_cast<int32_t*>(base + (uint32_t)sp) = v; sp += (int32_t)stride; }
+	__device__ __forceinline__ int32_t pop(int32_t& sp) const { sp -= (int32_t)stride; return *reinterpret_cast<const int32_t*>(base + (uint32_t)sp); }
+};
+
 template <typename Real> struct Trav {
 	int32_t cur;      // >= 0 inner node, < 0 leaf code, kDone when finished
-	int32_t sp;
+	int32_t sp;       // in the stack's own unit, see StackLds / StackMem
 	Real best_t;
 	int32_t best_prim;  // index into prims, -1 = none
 };
-RT_FN void trav_begin(Trav<Real>& tv) {
-	tv.cur = 0; tv.sp = 0; tv.best_t = Fp<Real>::max_finite(); tv.best_prim = -1;
+RT_FN void trav_begin(Trav<Real>& tv, int32_t stack_bottom) {
+	tv.cur = 0; tv.sp = stack_bottom; tv.best_t = Fp<Real>::max_finite(); tv.best_prim = -1;
 }
 struct Tally { uint32_t box, sphere, cube; };
 // Instrumented builds only: per code region, the lane-iterations executed (sum over active
 // lanes) and the wave-iterations issued (counted by the first active lane), whose ratio / 64
 // is the SIMD lane utilisation of that region.
-enum : int { kRegInner = 0, kRegSphere, kRegCube, kRegLeaf, kRegShade, kRegSky, kRegLambert, kRegMetal, kRegGlass, kRegStart, kRegTravRound, kRegCount };
+enum : int { kRegInner = 0, kRegSphere, kRegCube, kRegLeaf, kRegShade, kRegSky, kRegLambert, kRegMetal, kRegGlass, kRegStart, kRegTravRound, kRegXPush, kRegXPop, kRegXFull, kRegXSpin, kRegCount };
 // Instrumented builds also clock the phases of the wave's main loop (s_memtime, wave-uniform).
-enum : int { kPhShade = 0, kPhRegen, kPhFresh, kPhInner, kPhLeaf, kPhTotal, kPhCount };
+enum : int { kPhShade = 0, kPhRegen, kPhFresh, kPhInner, kPhLeaf, kPhXchg, kPhTotal, kPhCount };
 struct Regions { uint32_t lane[kRegCount], wave[kRegCount]; unsigned long long clk[kPhCount]; };
 template <bool kCount>
 __device__ __forceinline__ unsigned long long phase_begin() {
@@ -494,19 +519,18 @@ __device__ __forceinline__ void region_tick(Regions& rg, int slot) {
 	}
 }
 
-template <typename Real, int kThreads>
-__device__ __forceinline__ void trav_pop(Trav<Real>& tv, const int* stack) {
-	if (tv.sp > 0) {
-		tv.sp--;
-		tv.cur = stack[tv.sp * kThreads];
+template <typename Real, typename Stack>
+__device__ __forceinline__ void trav_pop(Trav<Real>& tv, const Stack& stack) {
+	if (tv.sp != stack.bottom()) {
+		tv.cur = stack.pop(tv.sp);
 	} else {
 		tv.cur = kDone;
 	}
 }
 // Descends inner nodes until the lane stands at a leaf or has run out of work, or until most
 // lanes that entered with it have (it then stays at its inner node for the next round).
-template <typename Real, int kThreads, bool kCount>
-__device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, int* stack, Tally& tally, Regions& rg,
+template <typename Real, typename Stack, bool kCount>
+__device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, const Stack& stack, Tally& tally, Regions& rg,
                                            int32_t inner_exit = 0) {
 	const int32_t min_lanes = ((int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit + 15) >> 4;  // fewer than inner_exit sixteenths of those that entered
 	while (tv.cur >= 0) {
@@ -520,22 +544,21 @@ __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& 
 		if (kCount && kTally) tally.box += 2;
 		if (hl && hr) {
 			bool right_first = er < el;  // nearer child first, the left one on equal entry
-			stack[tv.sp * kThreads] = right_first ? cl : cr;
-			tv.sp++;
+			stack.push(tv.sp, right_first ? cl : cr);
 			tv.cur = right_first ? cr : cl;
 		} else if (hl) {
 			tv.cur = cl;
 		} else if (hr) {
 			tv.cur = cr;
 		} else {
-			trav_pop<Real, kThreads>(tv, stack);
+			trav_pop<Real>(tv, stack);
 		}
 	}
 }
 // The same descent over quantised nodes (f32 trees in global memory): two 16-byte loads per
 // visit instead of four, twelve conversions more.
-template <int kThreads, bool kCount>
-__device__ __forceinline__ void trav_inner_q(Trav<float>& tv, const TravRay<float>& r, const QNode* nodes, int* stack, Tally& tally, Regions& rg,
+template <typename Stack, bool kCount>
+__device__ __forceinline__ void trav_inner_q(Trav<float>& tv, const TravRay<float>& r, const QNode* nodes, const Stack& stack, Tally& tally, Regions& rg,
                                              int32_t inner_exit) {
 	const int32_t min_lanes = ((int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit + 15) >> 4;
 	while (tv.cur >= 0) {
@@ -557,15 +580,14 @@ __device__ __forceinline__ void trav_inner_q(Trav<float>& tv, const TravRay<floa
 		if (kCount && kTally) tally.box += 2;
 		if (hl && hr) {
 			bool right_first = er < el;
-			stack[tv.sp * kThreads] = right_first ? cl : cr;
-			tv.sp++;
+			stack.push(tv.sp, right_first ? cl : cr);
 			tv.cur = right_first ? cr : cl;
 		} else if (hl) {
 			tv.cur = cl;
 		} else if (hr) {
 			tv.cur = cr;
 		} else {
-			trav_pop<float, kThreads>(tv, stack);
+			trav_pop<float>(tv, stack);
 		}
 	}
 }
@@ -603,10 +625,10 @@ __device__ __forceinline__ void leaf_tests(Trav<Real>& tv, const TravRay<Real>& 
 		if (hit_cube<Real>(prims[i], r, &t) && better(t, i)) { tv.best_t = t; tv.best_prim = i; }
 	}
 }
-template <typename Real, int kThreads, bool kCount>
-__device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, const Gate<Real>* gates, int* stack, Tally& tally, Regions& rg) {
+template <typename Real, typename Stack, bool kCount>
+__device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, const Gate<Real>* gates, const Stack& stack, Tally& tally, Regions& rg) {
 	leaf_tests<Real, kCount>(tv, r, tv.cur, prims, gates, tally, rg);
-	trav_pop<Real, kThreads>(tv, stack);
+	trav_pop<Real>(tv, stack);
 }
 
 // BVH::trace, src/bvh.rs:130-142, with get_normal of src/shapes/sphere.rs:60-62 and
@@ -788,6 +810,49 @@ __device__ __forceinline__ bool decode_path(uint32_t item, uint32_t j, uint32_t 
 enum : int { kIdle = 0, kTraverse = 1, kShade = 2, kFresh = 3 };
 
 // ---------------------------------------------------------------------------------------
+// Exchange queues (kXchg): rays that wait to be shaded change lanes, and waves, so that one
+// shading step serves one kind of ray.  The shading code has three arms that a wave runs one
+// after the other, each on the lanes that take it: a miss (sky, sample to the accumulation
+// buffer), a Lambertian or metal hit, a glass hit; a wave that leaves its traversal loop holds
+// a mix of all three.  With the queues, the lanes of the minority arms put their rays into the
+// workgroup's queue for that arm (80 bytes of LDS per ray) and free lanes take rays of the
+// majority arm out of its queue, so the step runs one arm on nearly every lane.  A queue that
+// is half full is served first whatever the wave holds.  Nothing waits for a queue: a ray that
+// finds its queue full is shaded where it is, as without the queues, and a wave only takes
+// what is there.  Which lane shades a ray does not change the ray, so images stay bit-identical.
+//
+// A queue is a ring of `cap` records claimed by tickets: `tail` hands out positions to writers
+// and `head` to readers, `space` and `avail` admit only as many of either as there are records
+// free or written, and every record carries the number of the position it is ready for
+// (seq == position: free for the writer of that position; position + 1: written, for its
+// reader; the reader leaves position + cap).  Waits are therefore only ever for a wave that is
+// in the middle of copying a record, never for one that has yet to decide something.
+// ---------------------------------------------------------------------------------------
+constexpr int kArms = 3;
+constexpr uint32_t kXchgRecBytes = 80;
+__device__ __forceinline__ uint32_t xchg_peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int32_t xchg_peek(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+struct Xchg {
+	char* base;      // control words, one 16-byte row per counter and a column per arm: avail, space, head, tail; then seq, then the records
+	uint32_t cap;
+	__device__ __forceinline__ int32_t* avail() const { return reinterpret_cast<int32_t*>(base); }
+	__device__ __forceinline__ int32_t* space() const { return reinterpret_cast<int32_t*>(base + 16); }
+	__device__ __forceinline__ uint32_t* head() const { return reinterpret_cast<uint32_t*>(base + 32); }
+	__device__ __forceinline__ uint32_t* tail() const { return reinterpret_cast<uint32_t*>(base + 48); }
+	// one counter of all arms at a glance (wave-uniform)
+	__device__ __forceinline__ int4 peek4(const int32_t* row) const {
+		return make_int4(__builtin_amdgcn_readfirstlane(xchg_peek(row)), __builtin_amdgcn_readfirstlane(xchg_peek(row + 1)), __builtin_amdgcn_readfirstlane(xchg_peek(row + 2)), 0);
+	}
+	__device__ __forceinline__ uint32_t* seq(int arm) const { return reinterpret_cast<uint32_t*>(base + 64) + (uint32_t)arm * cap; }
+	__device__ __forceinline__ uint4* rec(int arm, uint32_t slot) const { return reinterpret_cast<uint4*>(base + 64 + kArms * cap * 4u + ((uint32_t)arm * cap + slot) * kXchgRecBytes); }
+};
+__host__ __device__ constexpr uint32_t xchg_bytes(uint32_t cap) { return 64u + kArms * cap * (4u + kXchgRecBytes); }
+// LDS operations of one wave are carried out in the order they were issued: a compiler barrier
+// between the record and its sequence word is all the ordering a writer needs, and likewise
+// between a reader's look at the sequence word and its loads of the record.
+__device__ __forceinline__ void xchg_order() { asm volatile("" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------
 // The megakernel.
 // ---------------------------------------------------------------------------------------
 // kLds: 0 = the scene is read from global memory; 1 = nodes, primitives and gates are copied to LDS;
@@ -799,16 +864,35 @@ enum : int { kIdle = 0, kTraverse = 1, kShade = 2, kFresh = 3 };
 // its tile belongs to one item at a time.  For scenes whose paths are a ray or two long, where the
 // accumulation atomics were what bounded the kernel (the three-object 4K scene ran at the same speed
 // with and without its camera's defocus arithmetic), and only where LDS has the room.
-template <typename Real, int kThreads, int kLds, bool kCount, bool kQ = false, bool kAccLds = false>
+// kStackMem: the lanes' traversal stacks in global memory (StackMem) instead of LDS.
+// kXchg: rays waiting to be shaded are regrouped by shading arm through queues in LDS (see Xchg).
+template <typename Real, int kThreads, int kLds, bool kCount, bool kQ = false, bool kAccLds = false, bool kStackMem = false, bool kXchg = false>
 __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? (kThreads == 1024 ? 8 : (kQ ? RT_QWAVES : RT_MINWAVES)) : 2)) void render_kernel(RenderArgs<Real> A) {
 	static_assert(!kQ || (kLds == 0 && std::is_same<Real, float>::value), "quantised nodes: f32 trees in global memory only");
+	static_assert(!kXchg || (kLds != 0 && !kAccLds && std::is_same<Real, float>::value), "exchange queues: f32, scene in LDS, no accumulation tiles");
 	extern __shared__ __align__(64) char smem[];
-	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kThreads]
-	const uint32_t stack_bytes = (uint32_t)A.stack_entries * kThreads * 4u;
+	using Stack = typename std::conditional<kStackMem, StackMem, StackLds<kThreads>>::type;
+	Stack stack;
+	uint32_t stack_bytes = 0;
+	if constexpr (kStackMem) {
+		stack.base = A.stack_mem;
+		stack.first = (blockIdx.x * (uint32_t)kThreads + threadIdx.x) * 4u;
+		stack.stride = gridDim.x * (uint32_t)kThreads * 4u;
+	} else {
+		stack.col = reinterpret_cast<int*>(smem) + threadIdx.x;  // [entry * kThreads]
+		stack_bytes = (uint32_t)A.stack_entries * kThreads * 4u;
+	}
 	const Node<Real>* nodes;
 	const Prim<Real>* prims;
 	const Mat<Real>* mats;
 	const Gate<Real>* gates;
+	Xchg xq{nullptr, 0u};
+	if constexpr (kXchg) {
+		xq.base = smem + A.xchg_off;
+		xq.cap = A.xchg_cap;
+		for (uint32_t i = threadIdx.x; i < kArms * xq.cap; i += kThreads) xq.seq(0)[i] = i & (xq.cap - 1u);
+		if (threadIdx.x < 16u) reinterpret_cast<uint32_t*>(xq.base)[threadIdx.x] = (threadIdx.x >> 2) == 1u ? xq.cap : 0u;
+	}
 	if constexpr (kLds) {
 		char* dst = smem + stack_bytes;
 		const uint4* src = reinterpret_cast<const uint4*>(A.scene);
@@ -879,8 +963,116 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	uint32_t spare_pos = 0, spare_end = 0;
 
 	for (;;) {
-		// ---- shading ---------------------------------------------------------------------
 		unsigned long long t_ph = phase_begin<kCount>();
+		// With the exchange queues, shading steps follow one another for as long as there are free
+		// lanes and a queue that can fill them: each step runs one arm.
+		for (;;) {
+		// ---- exchange: one shading arm per step ---------------------------------------------
+		if constexpr (kXchg) {
+			int arm = -1;
+			if (state == kShade) arm = tv.best_prim < 0 ? 0 : ((((prims[tv.best_prim].id >> kMatShift) & 3) == RTHIP_DIELECTRIC) ? 2 : 1);
+			const unsigned long long m_arm[kArms] = {__ballot(arm == 0), __ballot(arm == 1), __ballot(arm == 2)};
+			const int32_t n_arm[kArms] = {(int32_t)__popcll(m_arm[0]), (int32_t)__popcll(m_arm[1]), (int32_t)__popcll(m_arm[2])};
+			const int32_t n_idle = (int32_t)__popcll(__ballot(state == kIdle));
+			const int4 av4 = xq.peek4(xq.avail()), sp4 = xq.peek4(xq.space());
+			const int32_t avail[kArms] = {max(0, av4.x), max(0, av4.y), max(0, av4.z)};
+			const int32_t space[kArms] = {sp4.x, sp4.y, sp4.z};
+			// the arm this step runs: the one that fills most lanes, counting what free lanes could take
+			// out of its queue and what cannot leave because its own queue is full; a queue at its
+			// half-way mark goes first
+			int best = 0, best_score = -1;
+			for (int k = 0; k < kArms; k++) {
+				int32_t room = n_idle;
+				for (int j = 0; j < kArms; j++) if (j != k && space[j] >= n_arm[j] && n_arm[j] <= A.xchg_push_max) room += n_arm[j];
+				const int32_t score = n_arm[k] + min(avail[k], room) + (avail[k] >= (int32_t)(xq.cap / 2u) ? 64 : 0);
+				if (score > best_score) { best_score = score; best = k; }
+			}
+			// the other arms' lanes hand their rays over (a full queue: they are shaded where they are)
+			for (int j = 0; j < kArms; j++) {
+				if (j == best || n_arm[j] == 0 || n_arm[j] > A.xchg_push_max) continue;
+				if (space[j] < n_arm[j]) {
+					if (arm == j) region_tick<kCount>(rg, kRegXFull);
+					continue;
+				}
+				int32_t had = 0;
+				uint32_t pos = 0;
+				if (lane == 0) {
+					had = atomicSub(xq.space() + j, n_arm[j]);
+					if (had >= n_arm[j]) pos = atomicAdd(xq.tail() + j, (uint32_t)n_arm[j]);
+					else atomicAdd(xq.space() + j, n_arm[j]);
+				}
+				had = __builtin_amdgcn_readfirstlane(had);
+				pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+				if (had < n_arm[j]) {
+					if (arm == j) region_tick<kCount>(rg, kRegXFull);
+					continue;
+				}
+				if (arm == j) {
+					region_tick<kCount>(rg, kRegXPush);
+					const uint32_t p = pos + lane_rank(m_arm[j]);
+					const uint32_t slot = p & (xq.cap - 1u);
+					uint32_t* sq = xq.seq(j) + slot;
+					while (xchg_peek(sq) != p) { region_tick<kCount>(rg, kRegXSpin); __builtin_amdgcn_s_sleep(1); }
+					xchg_order();
+					uint4* r = xq.rec(j, slot);
+					r[0] = make_uint4(__float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z), __float_as_uint(ray.d.x));
+					r[1] = make_uint4(__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(tv.best_t), (uint32_t)tv.best_prim);
+					r[2] = make_uint4(__float_as_uint(T.x), __float_as_uint(T.y), __float_as_uint(T.z), __float_as_uint(L.x));
+					r[3] = make_uint4(__float_as_uint(L.y), __float_as_uint(L.z), rng.state, rng.inc);
+					r[4] = make_uint4(accum_index, (uint32_t)depth, sample_slot, 0u);
+					xchg_order();
+					__hip_atomic_store(sq, p + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					state = kIdle;
+				}
+				xchg_order();
+				if (lane == 0) atomicAdd(xq.avail() + j, n_arm[j]);
+			}
+			// free lanes take rays of the chosen arm: enough of them to be worth the step, or whatever
+			// there is once the wave has no other work
+			const unsigned long long m_free = __ballot(state == kIdle);
+			const int32_t want = min((int32_t)__popcll(m_free), avail[best]);
+			const bool starving = queue_dry && pool_pos == pool_end && spare_pos == spare_end;
+			if (want > 0 && (want >= A.xchg_pop_min || starving)) {
+				int32_t had = 0;
+				uint32_t pos = 0;
+				if (lane == 0) {
+					had = atomicSub(xq.avail() + best, want);
+					if (had >= want) pos = atomicAdd(xq.head() + best, (uint32_t)want);
+					else atomicAdd(xq.avail() + best, want);
+				}
+				had = __builtin_amdgcn_readfirstlane(had);
+				pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+				if (had >= want) {
+					const uint32_t rk = lane_rank(m_free);
+					if (state == kIdle && rk < (uint32_t)want) {
+						region_tick<kCount>(rg, kRegXPop);
+						const uint32_t p = pos + rk;
+						const uint32_t slot = p & (xq.cap - 1u);
+						uint32_t* sq = xq.seq(best) + slot;
+						while (xchg_peek(sq) != p + 1u) { region_tick<kCount>(rg, kRegXSpin); __builtin_amdgcn_s_sleep(1); }
+						xchg_order();
+						const uint4* r = xq.rec(best, slot);
+						const uint4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
+						xchg_order();
+						__hip_atomic_store(sq, p + xq.cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						ray.o = mk<Real>(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+						ray.d = mk<Real>(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+						tv.best_t = __uint_as_float(q1.z); tv.best_prim = (int32_t)q1.w;
+						T = mk<Real>(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z));
+						L = mk<Real>(__uint_as_float(q2.w), __uint_as_float(q3.x), __uint_as_float(q3.y));
+						rng.state = q3.z; rng.inc = q3.w;
+						accum_index = q4.x; depth = (int32_t)q4.y; sample_slot = q4.z;
+						state = kShade;
+					}
+					xchg_order();
+					if (lane == 0) atomicAdd(xq.space() + best, want);
+				}
+			}
+		}
+		phase_end<kCount>(rg, kPhXchg, t_ph);
+		t_ph = phase_begin<kCount>();
+		// ---- shading ---------------------------------------------------------------------
+		const bool any_shade = __ballot(state == kShade) != 0ull;
 		if (state == kShade) {
 			region_tick<kCount>(rg, kRegShade);
 			if constexpr (kCount && kTally) {  // which arm of the shading code each lane takes: the arms run one after the other
@@ -912,6 +1104,19 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				}
 				state = kIdle;
 			}
+		}
+		if constexpr (!kXchg) break;
+		else {
+			// another step?  Only after one that shaded something (so that a queue nobody can take from ends
+			// the loop), with free lanes and a queue that holds enough for them.
+			if (!any_shade) break;
+			const int32_t n_free = (int32_t)__popcll(__ballot(state == kIdle));
+			if (n_free < A.xchg_pop_min) break;
+			const int4 av4 = xq.peek4(xq.avail());
+			if (max(max(av4.x, av4.y), av4.z) < A.xchg_pop_min) break;
+			phase_end<kCount>(rg, kPhShade, t_ph);
+			t_ph = phase_begin<kCount>();
+		}
 		}
 
 		phase_end<kCount>(rg, kPhShade, t_ph);
@@ -1025,11 +1230,17 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			}
 		}
 		phase_end<kCount>(rg, kPhRegen, t_ph);
-		if (__ballot(state != kIdle) == 0ull) break;
+		if (__ballot(state != kIdle) == 0ull) {
+			if constexpr (kXchg) {  // the wave is out of paths: what still waits in the queues is its work too
+				const int4 av4 = xq.peek4(xq.avail());
+				if (max(max(av4.x, av4.y), av4.z) > 0) continue;
+			}
+			break;
+		}
 		t_ph = phase_begin<kCount>();
 		// rays made above by shading (next bounce) and by regeneration (camera rays) are set up together
 		if (state == kFresh) {
-			trav_begin<Real>(tv);
+			trav_begin<Real>(tv, stack.bottom());
 			if constexpr (kQ) ray = prepare<Real>(RayT<Real>{ray.o, ray.d}, &A.qframe);
 			else ray = prepare<Real>(RayT<Real>{ray.o, ray.d});
 			// The oversized primitives (ground slab, sun) first: every ray tests them, here the lanes
@@ -1055,15 +1266,21 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				const bool paths_at_hand = !kAccLds || pool_pos != pool_end || (kBatchRegen && spare_pos != spare_end);
 				const bool refill = !queue_dry && paths_at_hand && (int32_t)__popcll(__ballot(state == kIdle)) >= A.regen_min;
 				if (refill || __ballot(state == kShade) != 0ull) break;
+				if constexpr (kXchg) {  // no paths left to start: idle lanes serve the queues
+					if (queue_dry && (int32_t)__popcll(__ballot(state == kIdle)) >= A.xchg_pop_min) {
+						const int4 av4 = xq.peek4(xq.avail());
+						if (max(max(av4.x, av4.y), av4.z) >= A.xchg_pop_min) break;
+					}
+				}
 			}
 			if (state == kTraverse) {
 				region_tick<kCount>(rg, kRegTravRound);
 				t_ph = phase_begin<kCount>();
-				if constexpr (kQ) trav_inner_q<kThreads, kCount>(tv, ray, reinterpret_cast<const QNode*>(A.scene + A.qnodes_off), stack, tally, rg, A.inner_exit);
-				else trav_inner<Real, kThreads, kCount>(tv, ray, nodes, stack, tally, rg, A.inner_exit);
+				if constexpr (kQ) trav_inner_q<Stack, kCount>(tv, ray, reinterpret_cast<const QNode*>(A.scene + A.qnodes_off), stack, tally, rg, A.inner_exit);
+				else trav_inner<Real, Stack, kCount>(tv, ray, nodes, stack, tally, rg, A.inner_exit);
 				phase_end<kCount>(rg, kPhInner, t_ph);
 				t_ph = phase_begin<kCount>();
-				if (tv.cur < 0 && tv.cur != kDone) trav_leaf<Real, kThreads, kCount>(tv, ray, prims, gates, stack, tally, rg);
+				if (tv.cur < 0 && tv.cur != kDone) trav_leaf<Real, Stack, kCount>(tv, ray, prims, gates, stack, tally, rg);
 				phase_end<kCount>(rg, kPhLeaf, t_ph);
 				if (tv.cur == kDone) state = kShade;
 			}
@@ -1093,7 +1310,8 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 template <typename Real>
 __global__ __launch_bounds__(kProbeBlock) void probe_kernel(ProbeArgs<Real> A) {
 	extern __shared__ __align__(64) char smem[];
-	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
+	using Stack = StackLds<kProbeBlock>;
+	const Stack stack{reinterpret_cast<int*>(smem) + threadIdx.x};
 	const Node<Real>* nodes = reinterpret_cast<const Node<Real>*>(A.scene);
 	const Prim<Real>* prims = reinterpret_cast<const Prim<Real>*>(A.scene + A.prims_off);
 	const Gate<Real>* gates = reinterpret_cast<const Gate<Real>*>(A.scene + A.gates_off);
@@ -1104,12 +1322,12 @@ __global__ __launch_bounds__(kProbeBlock) void probe_kernel(ProbeArgs<Real> A) {
 	rng.init(A.seed, i, A.sample);
 	TravRay<Real> ray = prepare<Real>(camera_ray<Real>(A.cam, (Real)px, (Real)py, rng, A.jitter != 0));
 	Trav<Real> tv;
-	trav_begin<Real>(tv);
+	trav_begin<Real>(tv, stack.bottom());
 	Tally tally{0, 0, 0};
 	Regions rg{};
 	while (tv.cur != kDone) {
-		trav_inner<Real, kProbeBlock, false>(tv, ray, nodes, stack, tally, rg);
-		if (tv.cur != kDone) trav_leaf<Real, kProbeBlock, false>(tv, ray, prims, gates, stack, tally, rg);
+		trav_inner<Real, Stack, false>(tv, ray, nodes, stack, tally, rg);
+		if (tv.cur != kDone) trav_leaf<Real, Stack, false>(tv, ray, prims, gates, stack, tally, rg);
 	}
 	if (tv.best_prim < 0) {
 		A.id[i] = -1; A.t[i] = 0.0; A.front[i] = 0;

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kThreads) void wf_extend(WfArgs<Real> A) {
 	if ((unsigned long long)blockIdx.x * kThreads >= n) return;
 
 	const uint32_t lane = threadIdx.x & 63u;
-	int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
+	using Stack = StackLds<kThreads>;
+	const Stack stack{reinterpret_cast<int*>(smem) + threadIdx.x};
 	const uint32_t stack_bytes = (uint32_t)A.stack_entries * kThreads * 4u;
 	const Node<Real>* nodes;
 	const Prim<Real>* prims;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void wf_extend(WfArgs<Real> A) {
 					index = pool_pos + rk;
 					Quad<Real> a = A.in.q0[index], b = A.in.q1[index];
 					ray = prepare<Real>(RayT<Real>{mk<Real>(a.x, a.y, a.z), mk<Real>(a.w, b.x, b.y)});
-					trav_begin<Real>(tv);
+					trav_begin<Real>(tv, stack.bottom());
 					busy = true;
 				}
 			}
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(kThreads) void wf_extend(WfArgs<Real> A) {
 		}
 		if (__ballot(busy) == 0ull) break;
 		if (busy) {
-			trav_inner<Real, kThreads, false>(tv, ray, nodes, stack, tally, rg);
-			if (tv.cur != kDone) trav_leaf<Real, kThreads, false>(tv, ray, prims, gates, stack, tally, rg);
+			trav_inner<Real, Stack, false>(tv, ray, nodes, stack, tally, rg);
+			if (tv.cur != kDone) trav_leaf<Real, Stack, false>(tv, ray, prims, gates, stack, tally, rg);
 			if (tv.cur == kDone) {
 				A.hit_t[index] = tv.best_t;
 				A.hit_prim[index] = tv.best_prim;

@@ -59,6 +59,10 @@ pub struct RthipStats {
     pub tree_depth: i32,
     pub scene_in_lds: i32,
     pub n_gates: i32,
+    pub launch_threads: i32,
+    pub launch_grid: i32,
+    pub launch_lds_bytes: i32,
+    pub waves_per_cu: i32,
 }
 
 #[repr(C)]

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(rt):
 def test_struct_layouts(rt):
     from raytracer_amd import _native as N
     assert N.OBJECT_DTYPE.itemsize == 88 and N.OBJECT_DTYPE.fields["param"][1] == 80
-    assert C.sizeof(N.CameraDesc) == 80 and C.sizeof(N.RenderParams) == 48 and C.sizeof(N.Stats) == 72
+    assert C.sizeof(N.CameraDesc) == 80 and C.sizeof(N.RenderParams) == 48 and C.sizeof(N.Stats) == 88
 
 
 def test_product_does_not_import_the_oracle():

@@ -27,5 +27,5 @@ for name in which:
         for _ in range(4):
             r.reset_accumulation(); r.accumulate(spp, spp_begin=0)
             s = r.stats(); best = max(best, s["paths"] / s["kernel_ms"] / 1e3)
-        print(f"{name} spp {spp} {spec:40s} {best:8.0f} Mpaths/s  threads {s.get('threads', '?')} grid {s.get('grid', '?')} nodes {s['n_nodes']} prims {s['n_prims']} depth {s['tree_depth']} lds {s['scene_in_lds']}", flush=True)
+        print(f"{name} spp {spp} {spec:40s} {best:8.0f} Mpaths/s  threads {s['launch_threads']} waves/CU {s['waves_per_cu']} lds {s['launch_lds_bytes']} nodes {s['n_nodes']} prims {s['n_prims']} depth {s['tree_depth']} in_lds {s['scene_in_lds']}", flush=True)
         r.close()

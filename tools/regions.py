@@ -1,16 +1,32 @@
-"""Instrumented run: SIMD lane utilisation per code region of the render kernel."""
+"""Instrumented run: SIMD lane utilisation per code region of the render kernel and the phase clocks
+of its main loop, per option set.
+  python tools/regions.py [--wl cfg2,cfg3] [--spp N] "-" "xchg=1" ...
+(RTHIP_LIBRARY picks a variant build, e.g. one compiled with -DRT_CLOCK_ONLY for undistorted phase shares.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
+WL = {"cfg2": ("default", 10), "cfg3": ("sample", 50)}
+args = sys.argv[1:]
+which, spp = ["cfg2", "cfg3"], 16
+while args and args[0] in ("--wl", "--spp"):
+    if args[0] == "--wl": which = args[1].split(",")
+    else: spp = int(args[1])
+    args = args[2:]
+sets = args or ["-"]
 os.environ["RTHIP_COUNT"] = "1"   # read when the context is created
-for which, scene, depth in (("cfg2", "default", 10), ("cfg3", "sample", 50)):
-    path = f"gpurun_out/regions_{which}.txt"
-    if os.path.exists(path): os.remove(path)
-    os.environ["RTHIP_REGION_DUMP"] = path
-    r = rt.Renderer(rt.Scene.generate(scene), rt.Camera(*CAM, 1920, 1080), max_depth=depth, seed=1)
-    r.accumulate(16)
-    s = r.stats()
-    print(which, s)
-    print(open(path).read())
-    r.close()
+for name in which:
+    scene, depth = WL[name]
+    sc = rt.Scene.generate(scene)
+    for spec in sets:
+        tag = spec.replace("=", "").replace(",", "_").replace("-", "base")
+        path = f"gpurun_out/regions_{name}_{tag}.txt"
+        if os.path.exists(path): os.remove(path)
+        os.environ["RTHIP_REGION_DUMP"] = path
+        opts = {} if spec == "-" else {k: float(v) for k, v in (kv.split("=") for kv in spec.split(","))}
+        r = rt.Renderer(sc, rt.Camera(*CAM, 1920, 1080), max_depth=depth, seed=1, options=opts)
+        r.accumulate(spp)
+        s = r.stats()
+        print(f"== {name} {spec}: {s['paths'] / s['kernel_ms'] / 1e3:.0f} Mpaths/s (instrumented) threads {s['launch_threads']} waves/CU {s['waves_per_cu']}")
+        print(open(path).read())
+        r.close()
