@@ -112,7 +112,11 @@ int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
 /* Tuning and build knobs (no counterpart in the reference, which has no configuration at all).
  * A context reads the RTHIP_* environment variables ONCE, in rthip_create; this call changes a
  * knob afterwards.  Names are the variable names in lower case without the prefix: launch knobs
- * "scene_lds", "qnodes", "threads", "blocks_per_cu", "grid_reserve", "chunk", "trav_threshold", "inner_exit",
+ * "scene_lds", "qnodes", "mats_lds" (materials in LDS beside the scene), "acc_lds" (per-wave accumulation
+ * tiles in LDS: -1 = scenes with nothing below the root, 0 = never, 1 = wherever they fit), "stack_mem"
+ * (1 = traversal stacks in global memory instead of LDS; measured slower, off), "xchg" (1 = rays waiting to
+ * be shaded are regrouped by kind through queues in LDS, with "xchg_cap", "xchg_pop_min", "xchg_push_max";
+ * measured slower, off), "threads", "blocks_per_cu", "grid_reserve", "chunk", "trav_threshold", "inner_exit",
  * "regen_min", "block_order", "wf_batch", "count" take effect with the next render call; build
  * knobs "tree_ref" (1 = device tree in the reference's shape), "tree_gpu" (1 = device tree built
  * on the GPU, a linear BVH with "gpu_leaf" primitives per leaf), "ref_gpu" (tie ranks, gates and primitive
@@ -120,7 +124,8 @@ int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
  * spheres and so many cubes per leaf, 0 = no cap), "sah_cprim",
  * "sah_sweep", "big_leaf_min", "no_big_leaf", "no_qnodes", "build_threads", "tie_reverse"
  * (1 = equal sort keys of BVH::new in reversed order, see rthip_bvh_leaf_order) with the next
- * rthip_scene_upload.  Unknown names return RTHIP_ERR_INVALID. */
+ * rthip_scene_upload.  Unknown names, and values that are not numbers in the int range, return
+ * RTHIP_ERR_INVALID. */
 int32_t rthip_set_option(rthip_ctx* ctx, const char* name, double value);
 
 /* Replaces BVH::new(scene) (src/bvh.rs:17-81): builds the reference-shaped median-split
@@ -131,12 +136,15 @@ int32_t rthip_scene_upload(rthip_ctx* ctx, const rthip_object* objects, int64_t 
  * is its only builder); for callers that move objects between frames.  `objects` are the objects of
  * the last rthip_scene_upload in the same order, at new places, sizes or materials: the same count,
  * each still a sphere or still a cube, the same ones impossible to hit (cubes with a negative half
- * extent), else RTHIP_ERR_INVALID and the scene on the device stays as it was.  The device tree keeps its shape
+ * extent), else RTHIP_ERR_INVALID and the scene on the device stays as it was (any OTHER failure of a
+ * refit, a HIP error or a limit, leaves the context without a usable scene: upload again).  The device tree keeps its shape
  * and its boxes are fitted again on the GPU, bottom up, one launch per level; tie ranks and gates are those
  * of the reference's tree over the objects as they now are, so every result equals that of a fresh
  * upload.  Far-reaching moves leave a tree that is sound but slow to walk: upload then.
  * `objects` may point into device memory (of the context's GPU) for both calls; a refit of a scene
- * of 2 048 objects and more then runs without a copy to or from the host. */
+ * of 2 048 objects and more then runs without a copy to or from the host.  Both calls read such
+ * objects on the context's stream only: whatever wrote them must be complete, or queued on that
+ * same stream (rthip_set_stream to the producer's stream, or a host wait), before the call. */
 int32_t rthip_scene_refit(rthip_ctx* ctx, const rthip_object* objects, int64_t n);
 /* Replaces Camera::new (src/camera.rs:25-69).  Changing the image size resets the
  * accumulation buffer; changing only the pose does not (callers reset, as
@@ -158,7 +166,9 @@ int32_t rthip_render_accumulate(rthip_ctx* ctx, const rthip_render_params* p);
 int32_t rthip_render_accumulate_async(rthip_ctx* ctx, const rthip_render_params* p);
 int32_t rthip_synchronize(rthip_ctx* ctx);
 /* The asynchronous render call for callers that cannot allocate device memory (code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart
+ * graph capture: on a capturing stream the call records only the clearing of its control block and the
+ * kernel, no events, and leaves the statistics of rthip_get_stats as they were; tight serving loops;
+ * harnesses that forbid hipMalloc).  It has no counterpart
  * in the reference.  It calls no hipMalloc, hipFree or other allocating routine: the control
  * block of the launch (work-queue counters and statistics, 1 KiB) lives in a 4 KiB array in
  * static device memory that every GPU holds from library load to process exit, instead of the
@@ -167,8 +177,12 @@ int32_t rthip_synchronize(rthip_ctx* ctx);
  * must already exist (rthip_camera_set or rthip_set_accum_buffer: RTHIP_ERR_STATE otherwise,
  * nothing is allocated for it).  All contexts on one GPU share that GPU's array and the array
  * keeps the last call's contents (the call clears what must start at zero, in stream order):
- * calls that overlap in time on one GPU, from two contexts or two streams, race.  Same
- * results, bit for bit, as rthip_render_accumulate_async. */
+ * two launches that overlap in time on one GPU would race, so a call made while the last launch
+ * through this entry point is still running on ANOTHER stream returns RTHIP_ERR_STATE and launches
+ * nothing (calls on one stream follow one another and are fine; replays of a captured graph are not
+ * seen by this check and are the caller's to keep apart).  A reduce in flight on the accumulation
+ * buffer (rthip_merge_reduce) is waited for on the stream first.  Same results, bit for bit, as
+ * rthip_render_accumulate_async. */
 int32_t rthip_render_accumulate_noalloc(rthip_ctx* ctx, const rthip_render_params* p);
 /* raytracer_runtime/src/main.rs:102-103 (accum_image cleared on a camera change). */
 int32_t rthip_reset_accumulation(rthip_ctx* ctx);

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <exception>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <tuple>
@@ -103,6 +104,7 @@ struct rthip_ctx {
 	int num_cu = 0;
 	hipStream_t own_stream = nullptr, stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipEvent_t noalloc_done = nullptr;  // recorded behind every launch of rthip_render_accumulate_noalloc
 	std::string err;
 
 	bool has_scene = false, has_camera = false;
@@ -233,9 +235,9 @@ int32_t replace_blob_tail(rthip_ctx* c, size_t n_nodes, const std::vector<Prim<R
 	if (total > 0xFFFFFFF0ull) return fail(c, RTHIP_ERR_LIMIT, "scene larger than 4 GiB");
 	if (prims_off != b->prims_off) return fail(c, RTHIP_ERR_INTERNAL, "refit: the primitives moved");
 	std::vector<char> host((size_t)(q_off - prims_off), 0);
-	std::memcpy(host.data(), prims.data(), (size_t)pb);
+	if (pb) std::memcpy(host.data(), prims.data(), (size_t)pb);  // (a scene in which nothing can be hit has no records: no null pointers into memcpy)
 	if (gb) std::memcpy(host.data() + (gates_off - prims_off), gates.data(), (size_t)gb);
-	std::memcpy(host.data() + (mats_off - prims_off), mats.data(), (size_t)mb);
+	if (mb) std::memcpy(host.data() + (mats_off - prims_off), mats.data(), (size_t)mb);
 	const bool same_place = gates_off == b->gates_off && mats_off == b->mats_off && total == b->bytes && (!qb || q_off == b->qnodes_off);
 	if (!same_place) {
 		char* fresh = nullptr;
@@ -250,7 +252,7 @@ int32_t replace_blob_tail(rthip_ctx* c, size_t n_nodes, const std::vector<Prim<R
 		b->lds_bytes = (uint32_t)mats_off;
 		b->lds_bytes_mats = align_up(mats_off + mb, 64);
 	}
-	HIP_TRY(c, hipMemcpy(b->dev + prims_off, host.data(), host.size(), hipMemcpyHostToDevice));
+	if (!host.empty()) HIP_TRY(c, hipMemcpy(b->dev + prims_off, host.data(), host.size(), hipMemcpyHostToDevice));
 	return RTHIP_OK;
 }
 
@@ -471,8 +473,12 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	return RTHIP_OK;
 }
 
+// `frugal` (rthip_render_accumulate_noalloc): nothing may be allocated, and the stream may be under
+// graph capture, where events cannot be queried afterwards: `timed` = false then leaves out the
+// timing events and the statistics of the launch.
 template <typename Real>
-int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, unsigned long long* accum, Real* samples_out, char* control = nullptr) {
+int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, unsigned long long* accum, Real* samples_out, char* control = nullptr,
+                       bool frugal = false, bool timed = true) {
 	if (!control) control = c->d_control;
 	Plan plan;
 	int32_t rc = make_plan(c, p, count, &plan);
@@ -505,6 +511,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 		const size_t need = (size_t)std::max(1, c->tree_depth) * (size_t)plan.cfg.grid * (size_t)plan.cfg.threads * 4;
 		if (need > 0xFFFFFFFFull) return fail(c, RTHIP_ERR_LIMIT, "traversal stacks in global memory exceed 4 GiB");
 		if (c->stack_mem_bytes < need) {
+			if (frugal) return fail(c, RTHIP_ERR_STATE, "rthip_render_accumulate_noalloc: the option stack_mem needs an array that no earlier call has allocated");
 			HIP_TRY(c, hipStreamSynchronize(c->stream));  // an earlier launch may still be using the old array
 			if (c->stack_mem) { HIP_TRY(c, hipFree(c->stack_mem)); c->stack_mem = nullptr; c->stack_mem_bytes = 0; }
 			HIP_TRY(c, hipMalloc(&c->stack_mem, need));
@@ -513,8 +520,9 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 		a.stack_mem = c->stack_mem;
 	}
 	HIP_TRY(c, hipMemsetAsync(control, 0, kControlBytes, c->stream));
-	HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+	if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
 	if (plan.n_items > 0 && p->spp_count > 0) HIP_TRY(c, launch_render(a, plan.cfg, c->stream));
+	if (!timed) return RTHIP_OK;  // a captured launch: its statistics stay in the control block, nobody reads them
 	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
 	c->launch_pending = true;
 	c->last_control = control;
@@ -658,6 +666,25 @@ int32_t ensure_accum(rthip_ctx* c) {
 
 }  // namespace
 
+namespace {
+// Who used a GPU's static control block last: the launches of all contexts on one GPU share it, and
+// two of them in flight at once on different streams would count in each other's work queues.
+struct ScratchUse {
+	std::mutex mu;
+	rthip_ctx* owner = nullptr;
+	hipStream_t stream = nullptr;
+	hipEvent_t done = nullptr;  // the owner's event, recorded behind its launch
+};
+ScratchUse g_scratch_use[64];
+// A context that goes away (its stream has been waited for) no longer stands for a launch in flight.
+void forget_scratch_use(rthip_ctx* c) {
+	if (c->device < 0 || c->device >= 64) return;
+	ScratchUse& use = g_scratch_use[c->device];
+	std::lock_guard<std::mutex> lock(use.mu);
+	if (use.owner == c) { use.owner = nullptr; use.stream = nullptr; use.done = nullptr; }
+}
+}  // namespace
+
 extern "C" {
 
 int32_t rthip_create(int32_t device, rthip_ctx** out) {
@@ -690,6 +717,7 @@ int32_t rthip_create(int32_t device, rthip_ctx** out) {
 		c->stream = c->own_stream;
 		if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
 		if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+		if ((e = hipEventCreateWithFlags(&c->noalloc_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
 		if ((e = hipMalloc(&c->d_control, kControlBytes)) != hipSuccess) return bail("hipMalloc", e);
 		// this device's copy of the static scratch array (the allocation-free entry point launches on it)
 		void* scratch = nullptr;
@@ -705,6 +733,7 @@ void rthip_destroy(rthip_ctx* c) {
 	try {
 		(void)hipSetDevice(c->device);
 		if (c->stream) (void)hipStreamSynchronize(c->stream);
+		forget_scratch_use(c);
 		if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
 		if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
 		if (c->comm) {
@@ -725,6 +754,7 @@ void rthip_destroy(rthip_ctx* c) {
 		if (c->wf_counters) (void)hipFree(c->wf_counters);
 		if (c->ev0) (void)hipEventDestroy(c->ev0);
 		if (c->ev1) (void)hipEventDestroy(c->ev1);
+		if (c->noalloc_done) (void)hipEventDestroy(c->noalloc_done);
 		if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 		delete c;
 	} catch (...) {
@@ -743,6 +773,7 @@ int32_t rthip_set_stream(rthip_ctx* c, void* hip_stream) {
 		int32_t rc = collect_stats(c);
 		if (rc != RTHIP_OK) return rc;
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		forget_scratch_use(c);
 		c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
 		return RTHIP_OK;
 	});
@@ -1103,10 +1134,36 @@ int32_t rthip_render_accumulate_noalloc(rthip_ctx* c, const rthip_render_params*
 		const uint64_t words = (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
 		if (!c->accum || c->accum_words != words)
 			return fail(c, RTHIP_ERR_STATE, "rthip_render_accumulate_noalloc: no accumulation buffer of the image's size is set (it will not allocate one)");
+		if (c->device < 0 || c->device >= 64) return fail(c, RTHIP_ERR_LIMIT, "rthip_render_accumulate_noalloc: device ordinal beyond 63");
 		HIP_TRY(c, hipSetDevice(c->device));
+		// a reduce still in flight on this buffer comes first (a stream wait: nothing is allocated)
+		if ((rc = wait_merges(c, c->accum)) != RTHIP_OK) return rc;
+		hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+		HIP_TRY(c, hipStreamIsCapturing(c->stream, &cap));
+		const bool capturing = cap != hipStreamCaptureStatusNone;
+		ScratchUse& use = g_scratch_use[c->device];
+		std::lock_guard<std::mutex> lock(use.mu);
+		// The block is free once the launch that used it last has finished, or when this launch is
+		// queued behind it on the same stream.  Anything else would be two launches sharing one set of
+		// work-queue counters: refused.  (A captured launch leaves no event behind: replays of a graph
+		// are the caller's to keep apart from other users of this entry point.)
+		if (use.owner && use.stream != c->stream) {
+			const hipError_t q = hipEventQuery(use.done);
+			if (q == hipErrorNotReady)
+				return fail(c, RTHIP_ERR_STATE, "rthip_render_accumulate_noalloc: another launch on this GPU is still using the static control block "
+				                                "(calls that overlap must share a stream, or use rthip_render_accumulate_async)");
+			if (q != hipSuccess) HIP_TRY(c, q);
+			use.owner = nullptr;
+		}
 		// the kernels take the scratch pointer as they take the allocated control block in rthip_render_accumulate_async
-		if (p->precision == RTHIP_F64) return enqueue_render<double>(c, p, false, c->accum, nullptr, c->static_control);
-		return enqueue_render<float>(c, p, false, c->accum, nullptr, c->static_control);
+		rc = p->precision == RTHIP_F64 ? enqueue_render<double>(c, p, false, c->accum, nullptr, c->static_control, true, !capturing)
+		                               : enqueue_render<float>(c, p, false, c->accum, nullptr, c->static_control, true, !capturing);
+		if (rc != RTHIP_OK) return rc;
+		if (!capturing) {
+			HIP_TRY(c, hipEventRecord(c->noalloc_done, c->stream));
+			use.owner = c; use.stream = c->stream; use.done = c->noalloc_done;
+		}
+		return RTHIP_OK;
 	});
 }
 
@@ -1163,17 +1220,24 @@ int32_t rthip_comm_init(rthip_ctx* c, const uint8_t id[128], int32_t rank, int32
 		const RcclApi* rccl = RcclApi::get(&why);
 		if (!rccl) return fail(c, RTHIP_ERR_STATE, why);
 		HIP_TRY(c, hipSetDevice(c->device));
-		if (c->comm) { (void)rccl->CommDestroy(c->comm); c->comm = nullptr; }
-		ncclUniqueId u;
-		std::memcpy(&u, id, 128);
-		ncclResult_t r = rccl->CommInitRank(&c->comm, world, u, rank);
-		if (r != ncclSuccess) { c->comm = nullptr; return fail(c, RTHIP_ERR_HIP, std::string("ncclCommInitRank: ") + rccl->GetErrorString(r)); }
-		c->comm_rank = rank; c->comm_world = world;
+		if (c->comm) {
+			// reduces still queued belong to the old communicator: let them finish before it goes
+			if (c->comm_stream) HIP_TRY(c, hipStreamSynchronize(c->comm_stream));
+			for (auto& m : c->merges) m.active = false;
+			(void)rccl->CommDestroy(c->comm);
+			c->comm = nullptr; c->comm_rank = -1; c->comm_world = 0;
+		}
 		if (!c->comm_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
 		for (auto& m : c->merges) {
 			if (!m.ready) HIP_TRY(c, hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
 			if (!m.done) HIP_TRY(c, hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
 		}
+		ncclUniqueId u;
+		std::memcpy(&u, id, 128);
+		ncclComm_t comm = nullptr;
+		ncclResult_t r = rccl->CommInitRank(&comm, world, u, rank);
+		if (r != ncclSuccess) return fail(c, RTHIP_ERR_HIP, std::string("ncclCommInitRank: ") + rccl->GetErrorString(r));
+		c->comm = comm; c->comm_rank = rank; c->comm_world = world;  // only once everything it needs exists
 		return RTHIP_OK;
 	});
 }

@@ -59,3 +59,83 @@ def test_noalloc_entry_point_matches_the_allocating_one(rt):
     r2.accumulate(3, spp_begin=0, noalloc=True)
     assert np.array_equal(buf.cpu().numpy().view(np.uint64), three)
     r2.close()
+
+
+def test_noalloc_overlap_on_two_streams_is_refused(rt):
+    """Two contexts on one GPU share the GPU's static control block: while a launch of one is still
+    running on its stream, a call from the other (another stream) returns RTHIP_ERR_STATE and launches
+    nothing; once the first has finished the same call goes through, and calls that share a stream
+    follow one another without a refusal."""
+    from raytracer_amd import _native as N
+    sc = rt.Scene.generate("default")
+    a = rt.Renderer(sc, rt.Camera(*camera_args("default", 960, 540, rt)), seed=5)
+    b = rt.Renderer(sc, rt.Camera(*camera_args("default", 96, 54, rt)), seed=5)
+    b.accumulate(2, spp_begin=0)
+    want = _words(b)
+    b.reset_accumulation()
+    b.synchronize()
+    a.accumulate(256, spp_begin=0, noalloc=True, sync=False)      # tens of milliseconds of work
+    p = b._params(0, 2)
+    rc = b._lib.rthip_render_accumulate_noalloc(b._ctx, C.byref(p))
+    assert rc == N.ERR_STATE, rc
+    assert b"static control block" in b._lib.rthip_last_error(b._ctx)
+    a.synchronize()
+    assert a.stats()["paths"] == 960 * 540 * 256                   # the refused call left the running launch alone
+    b.accumulate(2, spp_begin=0, noalloc=True)
+    assert np.array_equal(_words(b), want)
+    # one stream for both contexts: the launches are ordered, nothing to refuse
+    import torch
+    s = torch.cuda.Stream()
+    a.set_torch_stream(s); b.set_torch_stream(s)
+    a.reset_accumulation(); b.reset_accumulation()
+    a.accumulate(64, spp_begin=0, noalloc=True, sync=False)
+    b.accumulate(2, spp_begin=0, noalloc=True, sync=False)
+    a.synchronize(); b.synchronize()
+    assert np.array_equal(_words(b), want)
+    a.close(); b.close()
+
+
+def test_noalloc_after_a_reduce_and_under_graph_capture(rt):
+    """A render through the allocation-free entry point queued right behind an RCCL reduce of the same
+    buffer waits for it (one-rank communicator: the words come back as rendered, twice the samples after
+    the second render); and the call can be captured into a HIP graph (torch.cuda.graph) whose replays
+    render the same words as the direct call."""
+    import torch
+    from raytracer_amd import distributed as D
+    sc = rt.Scene.generate("default")
+    r = rt.Renderer(sc, rt.Camera(*camera_args("default", 320, 180, rt)), seed=9)
+    r.accumulate(3, spp_begin=0); r.accumulate(3, spp_begin=3)
+    six = _words(r)
+    r.reset_accumulation()
+    r.comm_init(rt.Renderer.comm_unique_id(), 0, 1)
+    r.accumulate(3, spp_begin=0, noalloc=True, sync=False)
+    r.merge_reduce(0)
+    r.accumulate(3, spp_begin=3, noalloc=True, sync=False)         # behind the reduce, on the render stream
+    r.synchronize()
+    assert np.array_equal(_words(r), six)
+    r.close()
+    # graph capture: a caller-owned buffer, the context on the capturing stream
+    g = rt.Renderer(sc, rt.Camera(*camera_args("default", 320, 180, rt)), seed=9)
+    buf = D.new_accum_tensor(320, 180, "cuda:0")
+    g.set_accum_buffer(buf.data_ptr(), buf.numel())
+    s = torch.cuda.Stream()
+    g.set_torch_stream(s)
+    with torch.cuda.stream(s):
+        g.accumulate(3, spp_begin=0, noalloc=True)                  # warm-up outside the capture (occupancy queries, attributes)
+        buf.zero_()
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        g.accumulate(3, spp_begin=0, noalloc=True, sync=False)
+        g.accumulate(3, spp_begin=3, noalloc=True, sync=False)
+    buf.zero_()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy().view(np.uint64), six)
+    buf.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy().view(np.uint64), six)
+    del graph
+    g.close()
