@@ -3,12 +3,16 @@
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torch.distributed.run)
 
 A step = one pass of the hot path over the workload: render the workload's `spp` samples of every
-pixel of its frame into an accumulation buffer resident in HBM.  With N > 1 GPUs the step's fixed
-sample budget is cut into N slices (strong scaling: rank r renders samples [r*spp/N, (r+1)*spp/N) of
-the full frame, `--split tile` cuts the 8x8 tiles instead), and ONE RCCL reduce of 64-bit integer
-words per step merges the ranks' buffers; it runs on a communication stream and overlaps the next
-step's tracing (two buffers in turn).  `--scaling weak` gives every GPU the whole budget instead.
-Rank 0 prints ONE JSON line.  The CPU legs (rank 0, N = 1) use the oracle as a measuring stick only.
+pixel of its frame into an accumulation buffer resident in HBM.  With N > 1 GPUs every GPU renders the
+whole workload, rank r the samples [r*spp, (r+1)*spp) of the same frame, and ONE RCCL reduce of 64-bit
+integer words per step merges the ranks' buffers into a frame of N x spp samples per pixel (weak
+scaling, the default: more GPUs buy more samples, and every GPU's launch stays the one BASELINE.json's
+config names).  The reduce runs on a communication stream and overlaps the next step's tracing (two
+buffers in turn).  The same line carries `strong_scaling`, measured in the same run: the step's fixed
+budget cut into N slices (rank r renders samples [r*spp/N, (r+1)*spp/N) of the full frame; `--split
+tile` cuts the 8x8 tiles instead), i.e. what N GPUs do for the time of ONE frame; `--scaling strong`
+makes that the headline.  Rank 0 prints ONE JSON line.  The CPU legs (rank 0, N = 1) use the oracle as a
+measuring stick only.
 """
 import argparse
 import json
@@ -118,13 +122,18 @@ def cpu_side(scene, wl, run_baseline, name):
         baseline = dict(value=c1["paths"] / s1 / 1e6, unit="Mpaths/s", cores=threads, kind="port",
                         sample=f"{sample}: {c1['paths']} paths in {s1:.1f} s; f64 restatement of the reference algorithm "
                                f"(recursive both-children BVH walk, per-axis AABB test), row-parallel on {threads} threads",
-                        mrays_per_s=c1["rays"] / s1 / 1e6)
+                        mrays_per_s=c1["rays"] / s1 / 1e6,
+                        # what the reference's walk costs per ray (its per-axis box test rejects almost nothing): beside the
+                        # minimal algorithm's count in `roofline`, this is the algorithmic part of any speed-up
+                        box_tests_per_ray=c1["box_tests"] / max(1, c1["rays"]),
+                        prim_tests_per_ray=(c1["sphere_tests"] + c1["cube_tests"]) / max(1, c1["rays"]))
         # the algorithm-matched figure on the same window; repeated until it has run for a second or so
         reps, secs, paths = 0, 0.0, 0
         while secs < 1.0 and reps < 64:
             _, _, c2, s2 = osc.render(cam_full, spp, wl["depth"], RENDER_SEED, ob.TIGHT, sky_mode=wl["sky"], threads=threads, window=win)
             reps, secs, paths = reps + 1, secs + s2, paths + c2["paths"]
         tight = dict(value=paths / secs / 1e6, unit="Mpaths/s", cores=threads, kind="port",
+                     box_tests_per_ray=c2["box_tests"] / max(1, c2["rays"]), prim_tests_per_ray=(c2["sphere_tests"] + c2["cube_tests"]) / max(1, c2["rays"]),
                      sample=f"{sample}, {reps} pass(es): {paths} paths in {secs:.2f} s; the same paths by the minimal standard algorithm "
                             f"(true slab test, near child first, culled by the best hit) on the reference-shaped tree")
     return work, baseline, tight
@@ -133,13 +142,42 @@ def cpu_side(scene, wl, run_baseline, name):
 def measured_traffic(name):
     """HBM bytes per path from rocprofv3 counters (FETCH_SIZE + WRITE_SIZE, corrected as the
     microarchitecture guide prescribes), measured per round by tools/profile.sh."""
-    for rel in ("profiles/r02/traffic.json", "profiles/traffic.json"):
+    for rel in ("profiles/r03/traffic.json", "profiles/r02/traffic.json", "profiles/traffic.json"):
         path = os.path.join(ROOT, rel)
         if os.path.exists(path):
             t = json.load(open(path)).get(name)
             if t:
-                return t["hbm_bytes_per_path"], rel
+                return t["hbm_bytes_per_path"], f"{rel} ({t.get('launch', '1920x1080 x 32 spp')})"
     return None, None
+
+
+def predicted_scaling(name):
+    """Best-case strong-scaling efficiency per GPU count from ONE GPU (tools/scaling_ceiling.py: the launches
+    an N-way split produces, timed back to back; the merge taken as hidden under the next step)."""
+    path = os.path.join(ROOT, "profiles/r03/scaling_ceiling.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path)).get(name)
+    if not d:
+        return None
+    return {"source": "profiles/r03/scaling_ceiling.json (one MI355X, tools/scaling_ceiling.py)", "ms_one_gpu": d["ms_one_gpu"],
+            "strong_spp_split_efficiency": {n: v["eff_spp_split"] for n, v in d["by_gpus"].items()},
+            "strong_tile_split_efficiency": {n: v["eff_tile_split"] for n, v in d["by_gpus"].items()},
+            "weak_efficiency": "1.0 less the merge that does not hide under the next step's tracing (every GPU runs the one-GPU launch)"}
+
+
+def measured_counters(name):
+    """Occupancy and divergence of the render kernel on this workload from the rocprofv3 counter passes
+    kept under profiles/ (tools/profile.sh, one 32-spp 1080p launch per pass): share of VALU lanes active
+    per issued instruction, resident waves per CU, share of wave cycles parked in s_waitcnt."""
+    for rel in (f"profiles/r03/{name}_pmc_summary.json", f"profiles/r02/{name}_pmc_summary.json"):
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            d = json.load(open(path))["derived"]
+            return {"valu_lane_utilisation": d.get("valu_lane_utilisation"), "resident_waves_per_cu": d.get("resident_waves_per_cu"),
+                    "wave_cycles_waiting": d.get("wave_cycles_waiting_s_waitcnt"), "wave_cycles_issuing": d.get("wave_cycles_issuing"),
+                    "salu_per_valu_instruction": d.get("salu_per_valu_instruction"), "source": rel}
+    return None
 
 
 def main():
@@ -149,8 +187,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel per step")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="N > 1: strong = the step's fixed budget is split over the GPUs (default); weak = every GPU renders the whole budget")
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
+                    help="N > 1: weak = every GPU renders the workload's whole budget, its own samples of the frame (default); "
+                         "strong = the step's fixed budget is split over the GPUs")
     ap.add_argument("--split", default="spp", choices=["spp", "tile"],
                     help="N > 1, strong scaling: spp = every GPU renders its slice of the samples of the full frame; "
                          "tile = every GPU renders all samples of its own 8x8 tiles")
@@ -190,13 +229,16 @@ def main():
     weak = args.scaling == "weak" and multi
     tile_split = args.split == "tile" and multi and not weak
 
-    def share(spp):
-        """(spp_begin, spp_count, tile part) of this rank for a step of `spp` samples."""
+    def share(spp, mode=None):
+        """(spp_begin, spp_count, tile part) of this rank for a step of `spp` samples; mode "weak",
+        "spp" or "tile" (default: what the command line asked for)."""
         if not multi:
             return 0, spp, (0, 1)
-        if weak:
+        if mode is None:
+            mode = "weak" if weak else "tile" if tile_split else "spp"
+        if mode == "weak":
             return rank * spp, spp, (0, 1)
-        if tile_split:
+        if mode == "tile":
             return 0, spp, D.tile_part(rank, world)
         begin, count = D.spp_slice(spp, rank, world)
         return begin, count, (0, 1)
@@ -214,7 +256,7 @@ def main():
                 r.set_option("grid_reserve", 48)   # room for the reduce kernel under the next step's render (the ABI merge reserves it by itself)
         return D.MergePipeline(make, dst=0)
 
-    def run_workload(name, steps, warmup, spp_override=0, precision=rt.F32):
+    def run_workload(name, steps, warmup, spp_override=0, precision=rt.F32, mode=None):
         wl = dict(WORKLOADS[name])
         if spp_override:
             wl["spp"] = spp_override
@@ -223,7 +265,7 @@ def main():
         r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"], precision=precision)
         r.set_torch_stream()
         pipe = make_pipeline(r, wl["width"], wl["height"])
-        begin, count, part = share(wl["spp"])
+        begin, count, part = share(wl["spp"], mode)
 
         def step():
             accum = pipe.acquire()   # the other buffer may still be in its reduce
@@ -324,6 +366,8 @@ def main():
     if multi:
         check = self_check()
     res = run_workload(args.workload, args.steps, args.warmup, args.spp)
+    # weak scaling is the headline; the fixed-budget split of the same workload is measured beside it
+    strong = run_workload(args.workload, args.steps, 1, args.spp, mode="tile" if args.split == "tile" else "spp") if weak else None
     wl = res["wl"]
     paths_per_step_all = wl["width"] * wl["height"] * wl["spp"] * (world if weak else 1)
     value = paths_per_step_all * args.steps / res["elapsed"] / 1e6
@@ -335,7 +379,7 @@ def main():
         line = {
             "metric": "Mpaths/s (path-tracing throughput, 1080p)", "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["elapsed"] / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling,   # (one GPU: the two are the same run) "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "spp_per_step": wl["spp"], "split": split_text, "merge": merge_kind["kind"],
                        "scene_objects": int(len(res["scene"])), "tree_depth": res["stats"]["tree_depth"], "scene_in_lds": res["stats"]["scene_in_lds"]},
             # ray segments of the last step (summed over the ranks) per second of step time
@@ -344,6 +388,17 @@ def main():
         }
         if check is not None:
             line["merge_self_check"] = "bit-identical to one GPU (256x144, 8 spp)" if check else "MISMATCH"
+        if strong is not None:
+            ws = strong["wl"]
+            line["strong_scaling"] = {
+                "value": ws["width"] * ws["height"] * ws["spp"] * args.steps / strong["elapsed"] / 1e6, "unit": "Mpaths/s",
+                "ms_per_step": strong["elapsed"] / args.steps * 1e3, "steps": args.steps,
+                "split": "tile" if args.split == "tile" else "spp",
+                "note": "the step's fixed budget of %d spp cut into %d shares, one reduce per step inside the timed region: the frame time N GPUs reach" % (ws["spp"], world)}
+        if multi:
+            pred = predicted_scaling(args.workload)
+            if pred:
+                line["predicted_scaling"] = pred
         if "frame_ms_1spp" in res:
             line["frame_ms_1080p_1spp"] = res["frame_ms_1spp"]
 
@@ -352,7 +407,11 @@ def main():
             wlx = rs["wl"]
             secs = rs["kernel_ms"] * 1e-3
             achieved = work["flop_per_path"] * rs["paths"] / secs / 1e12
-            per_path, src = measured_traffic(name)
+            per_path, src = measured_traffic(f"{name}_8k" if name == "cfg5" else name)   # cfg5: counters of the bench's own 8K launch
+            if per_path is None:
+                per_path, src = measured_traffic(name)
+                if per_path is not None and name == "cfg5":
+                    src += " -- a 1080p launch's bytes per path applied to the 8K launch: an estimate"
             traffic = per_path * rs["paths"] if per_path else None
             valu = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "traffic_source": src, "kernel": "render_kernel<float>",
@@ -365,6 +424,12 @@ def main():
                 flop_exec = work["flop_per_path"] - work["traversal_flop_per_path"] + ex["traversal_flop_per_path"]
                 valu.update(frac_executed=flop_exec * rs["paths"] / secs / 1e12 / PEAK_FP32_VALU_TFLOPS, executed_flop_per_path=flop_exec,
                             executed_box_tests_per_ray=ex["box_tests_per_ray"], executed_prim_tests_per_ray=ex["prim_tests_per_ray"])
+            st = rs["stats"]
+            valu["launch"] = {"threads_per_workgroup": st["launch_threads"], "workgroups": st["launch_grid"], "lds_bytes_per_workgroup": st["launch_lds_bytes"],
+                              "waves_per_cu_planned": st["waves_per_cu"]}
+            counters = measured_counters(name)
+            if counters:
+                valu["counters"] = counters
             out = {"roofline": valu}
             hbm_alg = wlx["width"] * wlx["height"] * 3 * 8 * 2   # one read-modify-write of every accumulation word
             if wlx["bound"] == "hbm" and ex:

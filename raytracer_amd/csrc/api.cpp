@@ -374,7 +374,7 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// resident waves (0.38 ms against 0.46 ms for that frame).
 	const bool short_launch = in_lds && !wavefront && my_tiles * kTilePixels * (uint64_t)p->spp_count < 512ull * 24 * (uint64_t)c->num_cu;
 	// Stacks in global memory: f32 megakernel with the scene in LDS (what the freed LDS is for is decided below).
-	const bool stack_mem = tune.stack_mem > 0 && in_lds && !f64 && !wavefront;
+	const bool stack_mem = tune.stack_mem > 0 && (in_lds || plan->cfg.quantised) && !f64 && !wavefront;
 	plan->cfg.stack_mem = stack_mem;
 	// Exchange queues: the same launches, long ones only (the queues pay once they have filled, and a
 	// launch's last rays leave them one wave at a time).
@@ -391,7 +391,7 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 		for (int threads : {256, 512, 768, 1024}) {
 			if (forced && threads != forced) continue;
 			if (short_launch && !forced && threads != 256) continue;
-			if (threads == 1024 && (wavefront || forced != 1024 || lds_mode == 2)) continue;  // 32 waves per CU at 64 VGPRs measured no faster than 24 at 80: on request only
+			if (threads == 1024 && (wavefront || forced != 1024 || (lds_mode != 0 && stack_mem) || lds_mode == 2)) continue;  // 32 waves per CU at 64 VGPRs measured no faster than 24 at 80: on request only
 			if (threads == 768 && lds_mode != 2) continue;  // two workgroups of twelve waves: only built for the variant that needs the room
 			size_t lds = (stack_mem ? 0 : (size_t)c->tree_depth * threads * 4) + (lds_mode == 2 ? blob.lds_bytes_mats : lds_mode == 1 ? blob.lds_bytes : 0);
 			const size_t xoff = align_up(lds, 64);
@@ -438,6 +438,20 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// and scatter a tile's accumulation lines).  Measured optimum: 4 up to ~128 spp, 8-16 beyond.
 	uint32_t auto_chunk = 4;
 	while (auto_chunk < 16 && auto_chunk * 64 <= p->spp_count) auto_chunk *= 2;
+	// ... and items of equal size: a launch's samples rarely divide by that figure, and the items of the
+	// last, short chunk of every tile cost nearly what full ones do (25 spp as 6 x 4 + 1: 7 % slower than
+	// 5 x 5; 13 spp as 3 x 4 + 1 against 5 + 5 + 3: 7 %).  Among the sizes from that figure up to just
+	// under its double, the one that leaves the fullest last chunk, the larger of equals.
+	if (p->spp_count > auto_chunk) {
+		uint32_t best = auto_chunk;
+		double best_fill = 0.0;
+		for (uint32_t cand = auto_chunk; cand < 2 * auto_chunk; cand++) {
+			const uint32_t n = (p->spp_count + cand - 1) / cand;
+			const double fill = (double)p->spp_count / ((double)n * cand);
+			if (fill >= best_fill) { best_fill = fill; best = cand; }
+		}
+		auto_chunk = best;
+	}
 	// Very short paths (a few objects under an open sky: 1.3 rays per path, two node visits each)
 	// spend a third of their time on accumulation atomics, and those run faster when a tile's
 	// samples follow one another: 32 samples per item gave 52 instead of 38 Gpaths/s on the

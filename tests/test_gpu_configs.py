@@ -9,9 +9,12 @@ buffer is 800 MB).
 import numpy as np
 import pytest
 
+from util import record_bar
+
 pytestmark = pytest.mark.gpu
 
 SCENE_SEED = 0x5EED0001
+F32_IDS_SHELLS = 1   # f32 primary-hit ids that may differ from the oracle's among 9 216 (measured 0: profiles/r03/f32_bars.txt)
 CFG5_CAMERA = ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0)   # bench.py cfg5
 
 
@@ -39,8 +42,8 @@ def test_cfg5_million_objects_f64_bit_exact_f32_ids(rt, oracle, million, million
             assert np.array_equal(a, b)
         g32 = r.trace_primary(rt.F32, jitter=jit, sample=3)
         wrong = int((g32[0] != ref[0]).sum())
-        print(f"[cfg5] jitter={int(jit)}: {wrong} of {w * h} f32 primary-hit ids differ from the oracle")
-        assert wrong <= 2e-3 * w * h
+        record_bar(f"[cfg5 million objects] jitter={int(jit)}: f32 ids differ {wrong} of {w * h}")
+        assert wrong <= 4   # measured 0-2: silhouettes of objects of radius 0.1-0.4 at coordinates ~500, where an f32 ulp is 3e-5
         same = (g32[0] == ref[0]) & (ref[0] >= 0)
         assert (np.abs(g32[1] - ref[1])[same] <= 1e-5 * ref[1][same]).all()
         assert np.abs(g32[2] - ref[2])[same].max() <= 1e-5
@@ -157,7 +160,9 @@ def test_many_gated_spheres(rt, oracle):
     for a, b in zip(ref, got):
         assert np.array_equal(a, b)
     g32 = r.trace_primary(rt.F32, jitter=True, sample=1)
-    assert (g32[0] != ref[0]).mean() <= 2e-3
+    wrong = int((g32[0] != ref[0]).sum())
+    record_bar(f"[300k hollow shells] f32 ids differ {wrong} of {ref[0].size}")
+    assert wrong <= F32_IDS_SHELLS
     _, smp, cnt, _ = osc.render(desc, 2, 12, 3, oracle.TIGHT, samples=True)
     assert np.array_equal(r.render_samples(2), smp) and r.stats()["rays"] == cnt["rays"]
     # f32 whole paths go through the gates of inner spheres on every refraction: same ray count to 1 %

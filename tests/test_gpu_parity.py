@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from util import SCENES, camera_args
+from util import SCENES, camera_args, record_bar
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -25,6 +25,10 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # pixels over the literal bar is printed per scene.
 F32_T_RTOL, F32_T_P50, F32_T_P99, F32_N_ATOL, F32_N_P99 = 1e-5, 2e-7, 5e-6, 5e-5, 2e-5
 LITERAL_BAR = 1e-5
+# f32 primary-hit ids that may differ from the oracle's on scenes of many small overlapping objects
+# (silhouette pixels): the measured count + 1 (profiles/r03/f32_bars.txt).  The six reference scenes: 0.
+F32_IDS_200K = 2           # of 5 184, measured 1
+F32_IDS_RANDOM = {6: 10}   # of 3 072 per seed: measured 9 on seed 6, 0 on the 23 others (bound 1)
 
 
 @pytest.fixture(scope="module")
@@ -80,6 +84,7 @@ def test_f32_probe_meets_the_literal_bar(rt, oracle, renderers, scene):
         assert np.abs(gn - rn)[hit].max() <= LITERAL_BAR
         assert np.array_equal(gf, rf)
         assert not gt[~hit].any() and not gn[~hit].any()
+        record_bar(f"[f32 probe] {scene} jitter={int(jit)}: ids differ 0 of {rid.size}; t max rel {rel.max():.2e}, normal max abs {np.abs(gn - rn)[hit].max():.2e}")
 
 
 @pytest.mark.parametrize("scene", SCENES)
@@ -103,8 +108,8 @@ def test_f32_raw_probe_within_conditioned_tolerance(rt, oracle, renderers, scene
         assert (dn <= F32_N_ATOL / np.maximum(cos, 1e-6)).all(), float((dn * cos).max())
         assert np.percentile(dn, 99) <= F32_N_P99
         assert np.array_equal(gf[same], rf[same])
-        print(f"[f32 raw] {scene} jitter={int(jit)}: {int((rel > LITERAL_BAR).sum())} of {int(same.sum())} hit pixels over 1e-5 in t "
-              f"(max {rel.max():.2e}), {int((dn > LITERAL_BAR).sum())} in a normal component (max {dn.max():.2e})")
+        record_bar(f"[f32 raw] {scene} jitter={int(jit)}: ids differ 0 of {rid.size}; {int((rel > LITERAL_BAR).sum())} of {int(same.sum())} hit pixels over 1e-5 in t "
+                   f"(max {rel.max():.2e}), {int((dn > LITERAL_BAR).sum())} in a normal component (max {dn.max():.2e})")
 
 
 @pytest.mark.parametrize("scene", SCENES)
@@ -296,7 +301,9 @@ def test_large_synthetic_scene_f64_vs_oracle(rt, oracle):
     got = r.render_samples(2)
     assert np.array_equal(got, smp) and r.stats()["scene_in_lds"] == 0
     g32 = r.trace_primary(rt.F32, jitter=True, sample=1)
-    assert (g32[0] != ref[0]).mean() <= 2e-3
+    wrong = int((g32[0] != ref[0]).sum())
+    record_bar(f"[200k synthetic] f32 ids differ {wrong} of {ref[0].size}")
+    assert wrong <= F32_IDS_200K
     r.close()
 
 
@@ -376,7 +383,7 @@ def test_f32_axis_parallel_rays_stay_cheap(rt):
 def test_random_scenes_f64_bit_exact_f32_close(rt, oracle, variant):
     """Random adversarial scenes (hollow shells, inverted spheres, coplanar and degenerate cubes,
     negative extents): f64 hits and whole paths bit-exact against the oracle; f32 primary hits
-    differ on at most 0.5 % of the pixels (silhouettes of many small overlapping objects)."""
+    differ on at most one pixel more than measured per seed (silhouettes of many small overlapping objects)."""
     from util import random_scene
     w, h = 64, 48
     for seed in range(24):
@@ -393,7 +400,9 @@ def test_random_scenes_f64_bit_exact_f32_close(rt, oracle, variant):
         assert np.array_equal(r.render_samples(2), smp, equal_nan=True), seed
         assert r.stats()["rays"] == cnt["rays"]
         g32 = r.trace_primary(rt.F32, jitter=True, sample=2)
-        assert (g32[0] != ref[0]).mean() <= 5e-3, seed
+        wrong = int((g32[0] != ref[0]).sum())
+        if variant != "wavefront": record_bar(f"[random scene {seed}] f32 ids differ {wrong} of {w * h}")
+        assert wrong <= F32_IDS_RANDOM.get(seed, 1), (seed, wrong)
         r.close()
 
 

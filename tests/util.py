@@ -4,6 +4,18 @@ import numpy as np
 SCENE_SEED = 0x5EED0001
 
 
+def record_bar(line):
+    """Measured f32 figures behind the asserted bounds (ids that differ from the oracle, pixels over the
+    literal 1e-5 bar): printed, and appended to gpurun_out/f32_bars.txt when that directory exists, so
+    that one run of the GPU suite leaves a record that can be kept under profiles/."""
+    import os
+    print(line)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "f32_bars.txt"), "a") as f:
+            f.write(line + "\n")
+
+
 def camera_args(name, w, h, rt):
     """Camera::new arguments per scene: the headless camera (raytracer_headless/src/main.rs:20-28)
     for the two grid scenes, the wgpu app's start pose (raytracer_gpu/src/main.rs:70) for the rest."""
