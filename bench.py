@@ -379,7 +379,7 @@ def main():
         line = {
             "metric": "Mpaths/s (path-tracing throughput, 1080p)", "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["elapsed"] / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling,   # (one GPU: the two are the same run) "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "spp_per_step": wl["spp"], "split": split_text, "merge": merge_kind["kind"],
                        "scene_objects": int(len(res["scene"])), "tree_depth": res["stats"]["tree_depth"], "scene_in_lds": res["stats"]["scene_in_lds"]},
             # ray segments of the last step (summed over the ranks) per second of step time
