@@ -60,6 +60,7 @@ struct Tuning {
 	int xchg_cap = 128;       // RTHIP_XCHG_CAP: records per queue (rounded down to a power of two, 64 at least)
 	int xchg_pop_min = 16;    // RTHIP_XCHG_POP_MIN
 	int xchg_push_max = 64;   // RTHIP_XCHG_PUSH_MAX
+	int root_leaf = 1;        // RTHIP_ROOT_LEAF: scenes with one leaf and no tree skip the traversal loop (0 = walk the root like any tree)
 	int acc_lds = -1;         // RTHIP_ACC_LDS: per-wave accumulation tiles in LDS: -1 = scenes with nothing below the root, 0 = never, 1 = wherever they fit
 	int threads = 0;          // RTHIP_THREADS: force the workgroup size (256, 512, 1024), 0 = most resident waves
 	int blocks_per_cu = 0;    // RTHIP_BLOCKS_PER_CU: cap on resident workgroups per CU, 0 = none
@@ -78,6 +79,7 @@ struct Tuning {
 		t.qnodes = env_int("RTHIP_QNODES", t.qnodes);
 		t.mats_lds = env_int("RTHIP_MATS_LDS", t.mats_lds);
 		t.acc_lds = env_int("RTHIP_ACC_LDS", t.acc_lds);
+		t.root_leaf = env_int("RTHIP_ROOT_LEAF", t.root_leaf);
 		t.stack_mem = env_int("RTHIP_STACK_MEM", t.stack_mem);
 		t.xchg = env_int("RTHIP_XCHG", t.xchg);
 		t.xchg_cap = env_int("RTHIP_XCHG_CAP", t.xchg_cap);
@@ -112,6 +114,7 @@ struct rthip_ctx {
 	int tree_depth = 0, n_nodes = 0, n_leaves = 0, n_prims = 0, n_gates = 0;
 	int64_t n_objects = 0;
 	int32_t big_leaf = 0, start = 0;  // leaf of oversized primitives tested at ray start, and the tree's entry after it
+	int32_t root_leaf = 0;            // the one leaf of a scene with nothing else below the root, 0 = the scene has a tree
 
 	CameraFields cam{};
 	int tiles_x = 0, tiles_y = 0;
@@ -505,6 +508,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.acc_tile_off = plan.cfg.acc_tile_off;
 	a.qnodes_off = blob.qnodes_off; a.qframe = blob.qframe;
 	a.big_leaf = c->big_leaf; a.start = c->start;
+	if (c->root_leaf != 0 && c->tune.root_leaf != 0) { a.big_leaf = c->root_leaf; a.start = kDone; }  // no tree: every ray tests the one leaf and is done
 	a.stack_entries = c->tree_depth;
 	fill_camera<Real>(c->cam, &a.cam);
 	a.width = c->cam.width; a.height = c->cam.height; a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y;
@@ -807,6 +811,7 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		else if (k == "qnodes") t.qnodes = iv;
 		else if (k == "mats_lds") t.mats_lds = iv;
 		else if (k == "acc_lds") t.acc_lds = iv;
+		else if (k == "root_leaf") t.root_leaf = iv;
 		else if (k == "stack_mem") t.stack_mem = iv;
 		else if (k == "xchg") t.xchg = iv;
 		else if (k == "xchg_cap") t.xchg_cap = iv;
@@ -977,6 +982,12 @@ int32_t rthip_scene_upload(rthip_ctx* c, const rthip_object* objects, int64_t n)
 			else c->blob32.qnodes_off = 0;
 		}
 		c->big_leaf = flat.big_leaf; c->start = flat.start;
+		// A scene whose root holds one leaf and nothing else (a handful of objects): the megakernel tests
+		// that leaf at ray start, like a leaf of oversized primitives, and has no tree to walk after it.
+		c->root_leaf = 0;
+		if (!flat.gpu.on && flat.big_leaf == 0 && flat.nodes32.size() == 1 && flat.nodes32[0].child[0] < 0 && flat.nodes32[0].child[0] != leaf_code(0, 0, 0) &&
+		    flat.nodes32[0].child[1] == leaf_code(0, 0, 0))
+			c->root_leaf = flat.nodes32[0].child[0];
 		c->tree_depth = flat.depth; c->n_nodes = flat.gpu.on ? flat.gpu.n_nodes : (int)flat.nodes32.size(); c->n_leaves = flat.n_leaves; c->n_prims = (int)n_prims;
 		c->n_gates = (int)n_gates;
 		c->n_objects = n;

@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				leaf_tests<Real, kCount>(tv, ray, A.big_leaf, prims, gates, tally, rg);
 				tv.cur = A.start;
 			}
-			state = kTraverse;
+			state = A.start == kDone ? kShade : kTraverse;  // (a scene that is one leaf: nothing to walk)
 		}
 		phase_end<kCount>(rg, kPhFresh, t_ph);
 

@@ -9,7 +9,7 @@ import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 sets = sys.argv[1:]
 bad = 0
-for scene, depth in (("default", 10), ("sample", 50), ("glass", 10)):
+for scene, depth in (("default", 10), ("sample", 50), ("glass", 10), ("wallpaper", 10)):
     sc = rt.Scene.generate(scene)
     ref = None
     for spec in ["-"] + sets:
