@@ -357,7 +357,7 @@ int32_t blocks_per_cu(rthip_ctx* c, bool f64, bool wavefront, int threads, int l
 	return RTHIP_OK;
 }
 
-int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* plan, bool wavefront = false) {
+int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* plan, bool wavefront = false, bool frugal = false) {
 	const bool f64 = p->precision == RTHIP_F64;
 	const SceneBlob& blob = f64 ? c->blob64 : c->blob32;
 	const Tuning& tune = c->tune;
@@ -377,7 +377,7 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// resident waves (0.38 ms against 0.46 ms for that frame).
 	const bool short_launch = in_lds && !wavefront && my_tiles * kTilePixels * (uint64_t)p->spp_count < 512ull * 24 * (uint64_t)c->num_cu;
 	// Stacks in global memory: f32 megakernel with the scene in LDS (what the freed LDS is for is decided below).
-	const bool stack_mem = tune.stack_mem > 0 && (in_lds || plan->cfg.quantised) && !f64 && !wavefront;
+	const bool stack_mem = tune.stack_mem > 0 && (in_lds || plan->cfg.quantised) && !f64 && !wavefront && !frugal;  // (the entry point that allocates nothing keeps its stacks in LDS)
 	plan->cfg.stack_mem = stack_mem;
 	// Exchange queues: the same launches, long ones only (the queues pay once they have filled, and a
 	// launch's last rays leave them one wave at a time).
@@ -498,7 +498,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
                        bool frugal = false, bool timed = true) {
 	if (!control) control = c->d_control;
 	Plan plan;
-	int32_t rc = make_plan(c, p, count, &plan);
+	int32_t rc = make_plan(c, p, count, &plan, false, frugal);
 	if (rc != RTHIP_OK) return rc;
 	const SceneBlob& blob = std::is_same<Real, double>::value ? c->blob64 : c->blob32;
 	RenderArgs<Real> a;
@@ -529,7 +529,6 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 		const size_t need = (size_t)std::max(1, c->tree_depth) * (size_t)plan.cfg.grid * (size_t)plan.cfg.threads * 4;
 		if (need > 0xFFFFFFFFull) return fail(c, RTHIP_ERR_LIMIT, "traversal stacks in global memory exceed 4 GiB");
 		if (c->stack_mem_bytes < need) {
-			if (frugal) return fail(c, RTHIP_ERR_STATE, "rthip_render_accumulate_noalloc: the option stack_mem needs an array that no earlier call has allocated");
 			HIP_TRY(c, hipStreamSynchronize(c->stream));  // an earlier launch may still be using the old array
 			if (c->stack_mem) { HIP_TRY(c, hipFree(c->stack_mem)); c->stack_mem = nullptr; c->stack_mem_bytes = 0; }
 			HIP_TRY(c, hipMalloc(&c->stack_mem, need));
