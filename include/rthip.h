@@ -161,9 +161,9 @@ int32_t rthip_camera_fields(const rthip_camera_desc* cam, double out[19]);
  * buffer.  Results do not depend on how samples or tiles are split over calls or GPUs. */
 int32_t rthip_render_accumulate(rthip_ctx* ctx, const rthip_render_params* p);
 /* Asynchronous form: enqueues on the context's stream and returns.  Statistics are valid
- * after rthip_synchronize.  (With variant RTHIP_WAVEFRONT the call still waits for the device
- * once every 8 bounces, to see whether any path is left before it queues the next launches: it
- * returns early only for the megakernel.) */
+ * after rthip_synchronize.  (With variant RTHIP_WAVEFRONT and max_depth beyond 64 the call waits
+ * for the device once every 64 bounces, to see whether any path is left before it queues the next
+ * launches; up to 64 bounces it returns without a wait, like the megakernel.) */
 int32_t rthip_render_accumulate_async(rthip_ctx* ctx, const rthip_render_params* p);
 int32_t rthip_synchronize(rthip_ctx* ctx);
 /* The asynchronous render call for callers that cannot allocate device memory (code under HIP

@@ -609,7 +609,10 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 			a.n_in = n + b; a.n_out = n + b + 1; a.fetch = fetch + b;
 			HIP_TRY(c, launch_wf_extend(a, plan.cfg, c->stream));
 			HIP_TRY(c, launch_wf_shade(a, stream_grid, c->stream));
-			if ((b & 7) == 7 && b + 1 < depth) {  // long paths: stop launching once the queue is empty
+			// Stages whose queue is empty return at once (a few microseconds of dispatch each), so paths of
+			// up to 64 bounces are queued without a look at the device; beyond that, one look every 64
+			// bounces stops the launches of a batch whose paths have all ended.
+			if ((b & 63) == 63 && b + 1 < depth) {
 				uint32_t left = 0;
 				HIP_TRY(c, hipMemcpyAsync(&left, n + b + 1, sizeof(left), hipMemcpyDeviceToHost, c->stream));
 				HIP_TRY(c, hipStreamSynchronize(c->stream));
