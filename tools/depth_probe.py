@@ -1,5 +1,8 @@
+"""Render time of a 32-spp 1080p launch of the two bench scenes against the depth limit (1, 2, 3, 4 and the
+workload's own), megakernel and wavefront variant: what the first segment of a path costs beside the later ones
+(a depth-1 render is camera rays only).  python tools/depth_probe.py"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 for scene, full in (("default", 10), ("sample", 50)):
