@@ -36,6 +36,13 @@
 
 typedef double Scalar;  // src/math.rs:4
 
+// Rust's f64::min / f64::max (src/math.rs:103, src/shapes/cube.rs:34-35) return the other operand when
+// one is NaN, which is what C's fmin / fmax do; written out here because without -ffinite-math-only the
+// compiler calls libm for them (five nanoseconds a call, a dozen calls per box test).  Which zero comes
+// back for (+0, -0) is not defined by either and decides nothing here: results are only compared.
+static inline Scalar fmin_(Scalar a, Scalar b) { return a < b ? a : (b != b ? a : b); }
+static inline Scalar fmax_(Scalar a, Scalar b) { return a > b ? a : (b != b ? a : b); }
+
 // ---------------------------------------------------------------------------------------
 // src/math.rs:18-318  Vec3 and its operators
 // ---------------------------------------------------------------------------------------
@@ -67,7 +74,7 @@ static inline Vec3 vabs(Vec3 a) { return V(std::fabs(a.x), std::fabs(a.y), std::
 static inline Vec3 reflect(Vec3 v, Vec3 n) { return v - ((n * 2.0) * dot(v, n)); }
 // math.rs:102-107 ; Rust f64::min ignores a NaN operand, as fmin does.
 static inline Vec3 refract(Vec3 uv, Vec3 n, Scalar etai_over_etat) {
-	Scalar cos_theta = std::fmin(dot(-uv, n), 1.0);
+	Scalar cos_theta = fmin_(dot(-uv, n), 1.0);
 	Vec3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
 	Vec3 r_out_parallel = -(std::sqrt(std::fabs(1.0 - length_squared(r_out_perp)))) * n;
 	return r_out_perp + r_out_parallel;
@@ -106,8 +113,8 @@ static inline bool aabb_hit_reference(const AABB& b, const Ray& ray) {
 }
 // math.rs:389-402 ; Rust f64::min/max ignore NaN like fmin/fmax.
 static inline AABB surrounding(const AABB& a, const AABB& b) {
-	return AABB{V(std::fmin(a.min.x, b.min.x), std::fmin(a.min.y, b.min.y), std::fmin(a.min.z, b.min.z)),
-	            V(std::fmax(a.max.x, b.max.x), std::fmax(a.max.y, b.max.y), std::fmax(a.max.z, b.max.z))};
+	return AABB{V(fmin_(a.min.x, b.min.x), fmin_(a.min.y, b.min.y), fmin_(a.min.z, b.min.z)),
+	            V(fmax_(a.max.x, b.max.x), fmax_(a.max.y, b.max.y), fmax_(a.max.z, b.max.z))};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -215,7 +222,7 @@ static inline bool scatter(const Material& m, const Ray& ray_in, const RayHit& h
 		Scalar ir = m.param;
 		Scalar refraction_ratio = hit.front_face ? 1.0 / ir : ir;
 		Vec3 unit_dir = normalize(ray_in.dir);
-		Scalar cos_theta = std::fmin(dot(-unit_dir, hit.normal), 1.0);
+		Scalar cos_theta = fmin_(dot(-unit_dir, hit.normal), 1.0);
 		Scalar sin_theta = std::sqrt(1.0 - (cos_theta * cos_theta));
 		bool cannot_refract = refraction_ratio * sin_theta > 1.0;
 		// `||` short-circuits: the draw happens only when the ray can refract (:54-55).
@@ -276,8 +283,8 @@ static inline bool cube_hit(const Object& cb, const Ray& ray, Scalar* t) {
 	Vec3 k = vabs(m) * cb.ext;
 	Vec3 t1 = -n - k;
 	Vec3 t2 = -n + k;
-	Scalar t_n = std::fmax(std::fmax(t1.x, t1.y), t1.z);
-	Scalar t_f = std::fmin(std::fmin(t2.x, t2.y), t2.z);
+	Scalar t_n = fmax_(fmax_(t1.x, t1.y), t1.z);
+	Scalar t_f = fmin_(fmin_(t2.x, t2.y), t2.z);
 	if (t_n > t_f || t_f <= 0. || t_n <= 0.) return false;
 	*t = t_n;
 	return true;
@@ -291,7 +298,7 @@ static inline Scalar rust_signum(Scalar x) { return std::isnan(x) ? x : std::cop
 static inline Vec3 object_normal(const Object& o, Vec3 p) {
 	if (o.kind == KIND_SPHERE) return (p - o.center) / o.ext.x;
 	Vec3 rel_p = p - o.center;
-	Scalar maxc = std::fmax(std::fmax(std::fabs(rel_p.x), std::fabs(rel_p.y)), std::fabs(rel_p.z));
+	Scalar maxc = fmax_(fmax_(std::fabs(rel_p.x), std::fabs(rel_p.y)), std::fabs(rel_p.z));
 	if (maxc == std::fabs(rel_p.x)) return V(rust_signum(rel_p.x), 0.0, 0.0);
 	if (maxc == std::fabs(rel_p.y)) return V(0.0, rust_signum(rel_p.y), 0.0);
 	return V(0.0, 0.0, rust_signum(rel_p.z));
@@ -368,8 +375,8 @@ static std::unique_ptr<BVH> bvh_new(std::vector<Object> objects, bool tie_revers
 	for (int axis = 0; axis < 3; axis++) {  // :28-43
 		Scalar bmin = DBL_MAX, bmax = -DBL_MAX;
 		for (const Object& o : objects) {
-			bmin = std::fmin(bmin, o.aabb.min[axis]);
-			bmax = std::fmax(bmax, o.aabb.max[axis]);
+			bmin = fmin_(bmin, o.aabb.min[axis]);
+			bmax = fmax_(bmax, o.aabb.max[axis]);
 		}
 		range[axis] = bmax - bmin;
 	}
@@ -467,8 +474,8 @@ static inline bool slab_test(const AABB& b, const Ray& ray, Vec3 inv, Scalar bes
 	Scalar tx0 = (b.min.x - ray.origin.x) * inv.x, tx1 = (b.max.x - ray.origin.x) * inv.x;
 	Scalar ty0 = (b.min.y - ray.origin.y) * inv.y, ty1 = (b.max.y - ray.origin.y) * inv.y;
 	Scalar tz0 = (b.min.z - ray.origin.z) * inv.z, tz1 = (b.max.z - ray.origin.z) * inv.z;
-	Scalar tnear = std::fmax(std::fmax(std::fmin(tx0, tx1), std::fmin(ty0, ty1)), std::fmin(tz0, tz1));
-	Scalar tfar = std::fmin(std::fmin(std::fmax(tx0, tx1), std::fmax(ty0, ty1)), std::fmax(tz0, tz1));
+	Scalar tnear = fmax_(fmax_(fmin_(tx0, tx1), fmin_(ty0, ty1)), fmin_(tz0, tz1));
+	Scalar tfar = fmin_(fmin_(fmax_(tx0, tx1), fmax_(ty0, ty1)), fmax_(tz0, tz1));
 	*entry = tnear;
 	tfar = tfar * kSlabPad;
 	return tnear <= tfar && tfar > 0.001 && tnear <= best_t * kSlabPad;
