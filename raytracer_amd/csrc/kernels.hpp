@@ -305,8 +305,16 @@ RT_FN TravRay<Real> prepare(RayT<Real> r, const QFrame* frame = nullptr) {
 // which keeps the discriminant accurate when |oc| >> r (small spheres far away, or the sun
 // sphere of radius 7500): b^2 - 4ac = 4a (r^2 - |q|^2) with q the closest approach to the centre.
 RT_FN bool hit_sphere(const Prim<Real>& s, const TravRay<Real>& r, Real* t) {
-	V3<Real> oc = r.o - ld3(s.v);
-	Real radius = s.v[3];
+	V3<Real> oc;
+	Real radius;
+	if constexpr (std::is_same<Real, float>::value) {
+		const float4 cr = *reinterpret_cast<const float4*>(s.v);  // centre and radius in one 16-byte load (records are 32-byte aligned)
+		oc = r.o - mk<Real>(cr.x, cr.y, cr.z);
+		radius = cr.w;
+	} else {
+		oc = r.o - ld3(s.v);
+		radius = s.v[3];
+	}
 	if constexpr (std::is_same<Real, float>::value) {
 		Real tc = dot(oc, r.d) * r.rcp_a;  // -(parameter of the closest approach)
 		V3<Real> q = oc - tc * r.d;
@@ -335,9 +343,12 @@ RT_FN bool hit_sphere(const Prim<Real>& s, const TravRay<Real>& r, Real* t) {
 RT_FN bool hit_cube(const Prim<Real>& c, const TravRay<Real>& r, Real* t) {
 	Real t_n, t_f;
 	if constexpr (std::is_same<Real, float>::value) {
-		float ax = (c.v[kBoxLoX] - r.o.x) * r.inv.x, bx = (c.v[kBoxHiX] - r.o.x) * r.inv.x;
-		float ay = (c.v[kBoxLoY] - r.o.y) * r.inv.y, by = (c.v[kBoxHiY] - r.o.y) * r.inv.y;
-		float az = (c.v[kBoxLoZ] - r.o.z) * r.inv.z, bz = (c.v[kBoxHiZ] - r.o.z) * r.inv.z;
+		static_assert(kBoxLoX == 0 && kBoxLoY == 1 && kBoxLoZ == 2 && kBoxHiX == 3 && kBoxHiY == 4 && kBoxHiZ == 5, "plane order of the loads below");
+		const float4 p0 = *reinterpret_cast<const float4*>(c.v);      // the six planes in a 16-byte and an 8-byte load
+		const float2 p1 = *reinterpret_cast<const float2*>(c.v + 4);
+		float ax = (p0.x - r.o.x) * r.inv.x, bx = (p0.w - r.o.x) * r.inv.x;
+		float ay = (p0.y - r.o.y) * r.inv.y, by = (p1.x - r.o.y) * r.inv.y;
+		float az = (p0.z - r.o.z) * r.inv.z, bz = (p1.y - r.o.z) * r.inv.z;
 		bool nx = r.inv.x < 0.0f, ny = r.inv.y < 0.0f, nz = r.inv.z < 0.0f;
 		t_n = Fp<float>::fmax(Fp<float>::fmax(nx ? bx : ax, ny ? by : ay), nz ? bz : az);
 		t_f = Fp<float>::fmin(Fp<float>::fmin(nx ? ax : bx, ny ? ay : by), nz ? az : bz);
