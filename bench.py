@@ -197,6 +197,9 @@ def main():
                     help="N > 1: abi = rthip_merge_reduce (ncclReduce through the C ABI), falling back to torch.distributed.reduce")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="run the N > 1 code path (process group, communicator, merge pipeline, self-check) with the ranks there are, even one")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal of the N > 1 path on a box with one GPU: every rank uses GPU 0 and the process group runs over gloo "
+                         "(RCCL refuses two ranks on one GPU, so the merge falls back from the C ABI to torch.distributed); not a measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the other configs, the f64 rate and the 1-spp frame")
     args = ap.parse_args()
@@ -215,17 +218,24 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     # Everything of this process (buffer zero-fills, renders, timing events) goes onto one stream of its
     # own: torch's default stream has the handle 0, which the C ABI reads as "the context's own stream",
     # and that one is not ordered against torch's operations.
     torch.cuda.set_stream(torch.cuda.Stream(device))
     multi = world > 1 or args.rehearse_dist
+    if args.one_device:
+        import faulthandler
+        faulthandler.dump_traceback_later(90, exit=False)   # a rehearsal that hangs says where
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     weak = args.scaling == "weak" and multi
     tile_split = args.split == "tile" and multi and not weak
 
@@ -251,7 +261,8 @@ def main():
             merge_kind["kind"] = "rthip_merge_reduce: ncclReduce(sum, uint64) through the C ABI, on a communication stream"
             return D.AbiMergePipeline(r, make, root=0)
         if multi:
-            merge_kind["kind"] = "torch.distributed.reduce(SUM, int64) over RCCL"
+            merge_kind["kind"] = ("all_reduce(SUM, int64) over gloo, staged through host memory (rehearsal)" if args.one_device else
+                                  "torch.distributed.reduce(SUM, int64) over RCCL")
             if world > 1:
                 r.set_option("grid_reserve", 48)   # room for the reduce kernel under the next step's render (the ABI merge reserves it by itself)
         return D.MergePipeline(make, dst=0)
@@ -262,7 +273,7 @@ def main():
             wl["spp"] = spp_override
         scene = rt.Scene.generate(wl["scene"], SCENE_SEED)
         cam = rt.Camera(*wl["camera"](), wl["width"], wl["height"])
-        r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"], precision=precision)
+        r = rt.Renderer(scene, cam, device=dev_index, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"], precision=precision)
         r.set_torch_stream()
         pipe = make_pipeline(r, wl["width"], wl["height"])
         begin, count, part = share(wl["spp"], mode)
@@ -277,6 +288,8 @@ def main():
         for _ in range(warmup):
             step()
         pipe.drain()
+        if multi and rank == 0:
+            log(f"{name}: {mode or ('weak' if weak else 'split')} run, warm-up done")
         kernel_ms = []
         rays = paths = 0
         if multi:
@@ -295,10 +308,11 @@ def main():
         elapsed = time.perf_counter() - t0
         stats = r.stats()
         if multi:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            coll = torch.device("cpu") if args.one_device else device   # gloo: host tensors
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            c = torch.tensor([stats["rays"], stats["paths"]], dtype=torch.int64, device=device)   # of every rank's last step
+            c = torch.tensor([stats["rays"], stats["paths"]], dtype=torch.int64, device=coll)   # of every rank's last step
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
             rays, paths = int(c[0].item()), int(c[1].item())
         out = dict(wl=wl, scene=scene, elapsed=elapsed, kernel_ms=float(np.mean(kernel_ms)) if kernel_ms else stats["kernel_ms"],
@@ -340,7 +354,7 @@ def main():
         w, h, spp = 256, 144, 8
         scene = rt.Scene.generate(wl["scene"] if len(wl["scene"]) < 12 else "default", SCENE_SEED)
         cam = rt.Camera(*wl["camera"](), w, h)
-        r = rt.Renderer(scene, cam, device=local_rank, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"])
+        r = rt.Renderer(scene, cam, device=dev_index, max_depth=wl["depth"], seed=RENDER_SEED, sky_mode=wl["sky"])
         r.set_torch_stream()
         pipe = make_pipeline(r, w, h)
         begin, count, part = (rank * spp, spp, (0, 1)) if weak else share(spp)
@@ -386,6 +400,8 @@ def main():
             "mrays_per_s": res["rays"] / (res["elapsed"] / args.steps) / 1e6,
             "rays_per_path": res["rays"] / max(1, res["paths"]),
         }
+        if args.one_device:
+            line["rehearsal"] = "--one-device: every rank on GPU 0, process group over gloo; the figures of this line are not measurements"
         if check is not None:
             line["merge_self_check"] = "bit-identical to one GPU (256x144, 8 spp)" if check else "MISMATCH"
         if strong is not None:

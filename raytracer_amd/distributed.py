@@ -38,10 +38,22 @@ def new_accum_tensor(width, height, device):
     return torch.zeros(accum_words(width, height), dtype=torch.int64, device=device)
 
 
+def _reduce(accum, dst, group, async_op=False):
+    """dist.reduce; under gloo a device buffer is summed through host memory with a blocking all_reduce
+    (rehearsals of the multi-rank path on one GPU: gloo's own handling of device tensors did not
+    finish there for frame-sized buffers); rank `dst` ends with the same sums either way."""
+    if accum.is_cuda and dist.get_backend(group) == "gloo":
+        host = accum.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        accum.copy_(host)
+        return None
+    return dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
 def merge_accum(accum, dst=0, group=None):
     """Sum every rank's accumulation buffer into rank `dst` (a single reduce)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        _reduce(accum, dst, group)
     return accum
 
 
@@ -74,7 +86,7 @@ class MergePipeline:
     def release(self):
         i = self.k % 2
         if self.active:
-            self.pending[i] = dist.reduce(self.bufs[i], dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending[i] = _reduce(self.bufs[i], self.dst, self.group, async_op=True)
         self.k += 1
         return self.bufs[i]
 
@@ -92,6 +104,8 @@ def init_abi_comm(renderer, rank, world, device):
     the caller merges through torch.distributed instead."""
     ok = 1
     raw = bytes(128)
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")   # the few bytes exchanged here need no device buffer
     if rank == 0:
         try:
             raw = renderer.comm_unique_id()
