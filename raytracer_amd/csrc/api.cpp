@@ -60,6 +60,7 @@ struct Tuning {
 	int xchg_cap = 128;       // RTHIP_XCHG_CAP: records per queue (rounded down to a power of two, 64 at least)
 	int xchg_pop_min = 16;    // RTHIP_XCHG_POP_MIN
 	int xchg_push_max = 64;   // RTHIP_XCHG_PUSH_MAX
+	int packet = 1;           // RTHIP_PACKET: the camera rays of a batch walk the tree together, as one packet per wave (f32 megakernel, scenes in global memory; 0 = each on its own)
 	int root_leaf = 1;        // RTHIP_ROOT_LEAF: scenes with one leaf and no tree skip the traversal loop (0 = walk the root like any tree)
 	int acc_lds = -1;         // RTHIP_ACC_LDS: per-wave accumulation tiles in LDS: -1 = scenes with nothing below the root, 0 = never, 1 = wherever they fit
 	int threads = 0;          // RTHIP_THREADS: force the workgroup size (256, 512, 1024), 0 = most resident waves
@@ -80,6 +81,7 @@ struct Tuning {
 		t.mats_lds = env_int("RTHIP_MATS_LDS", t.mats_lds);
 		t.acc_lds = env_int("RTHIP_ACC_LDS", t.acc_lds);
 		t.root_leaf = env_int("RTHIP_ROOT_LEAF", t.root_leaf);
+		t.packet = env_int("RTHIP_PACKET", t.packet);
 		t.stack_mem = env_int("RTHIP_STACK_MEM", t.stack_mem);
 		t.xchg = env_int("RTHIP_XCHG", t.xchg);
 		t.xchg_cap = env_int("RTHIP_XCHG_CAP", t.xchg_cap);
@@ -523,6 +525,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.queue = reinterpret_cast<uint32_t*>(control + 512);
 	a.stats = reinterpret_cast<unsigned long long*>(control + 8);
 	a.xchg_off = plan.xchg_off; a.xchg_cap = plan.xchg_cap;
+	a.packet = (c->tune.packet != 0 && c->tree_depth <= 64) ? 1 : 0;   // the wave's stack holds an entry per lane
 	a.xchg_pop_min = std::max(1, std::min(64, c->tune.xchg_pop_min));
 	a.xchg_push_max = std::max(0, std::min(64, c->tune.xchg_push_max));
 	if (plan.cfg.stack_mem) {
@@ -634,13 +637,13 @@ int32_t collect_stats(rthip_ctx* c) {
 	unsigned long long s[5 + 2 * kRegCount + kPhCount];
 	HIP_TRY(c, hipMemcpy(s, (c->last_control ? c->last_control : c->d_control) + 8, sizeof(s), hipMemcpyDeviceToHost));
 	if (!c->tune.region_dump.empty() && c->tune.count) {  // instrumented runs: lane utilisation per code region
-		static const char* names[kRegCount] = {"inner", "sphere", "cube", "leaf", "shade", "sky", "lambert", "metal", "glass", "start", "trav_round", "xchg_push", "xchg_pop", "xchg_full", "xchg_spin"};
+		static const char* names[kRegCount] = {"inner", "sphere", "cube", "leaf", "shade", "sky", "lambert", "metal", "glass", "start", "trav_round", "xchg_push", "xchg_pop", "xchg_full", "xchg_spin", "packet"};
 		if (FILE* f = std::fopen(c->tune.region_dump.c_str(), "a")) {
 			for (int k = 0; k < kRegCount; k++)
 				std::fprintf(f, "%s lane_iters %llu wave_iters %llu util %.3f\n", names[k], s[5 + k], s[5 + kRegCount + k],
 				             s[5 + kRegCount + k] ? (double)s[5 + k] / (64.0 * (double)s[5 + kRegCount + k]) : 0.0);
 			// wave clock ticks (s_memtime) per phase of the main loop, summed over the waves, and their share of the waves' lifetime
-			static const char* phases[kPhCount] = {"shade", "regen", "fresh", "inner", "leaf", "xchg", "total"};
+			static const char* phases[kPhCount] = {"shade", "regen", "fresh", "inner", "leaf", "xchg", "packet", "total"};
 			for (int k = 0; k < kPhCount; k++)
 				std::fprintf(f, "phase %s ticks %llu share %.3f\n", phases[k], s[5 + 2 * kRegCount + k],
 				             s[5 + 2 * kRegCount + kPhTotal] ? (double)s[5 + 2 * kRegCount + k] / (double)s[5 + 2 * kRegCount + kPhTotal] : 0.0);
@@ -814,6 +817,7 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		else if (k == "mats_lds") t.mats_lds = iv;
 		else if (k == "acc_lds") t.acc_lds = iv;
 		else if (k == "root_leaf") t.root_leaf = iv;
+		else if (k == "packet") t.packet = iv;
 		else if (k == "stack_mem") t.stack_mem = iv;
 		else if (k == "xchg") t.xchg = iv;
 		else if (k == "xchg_cap") t.xchg_cap = iv;

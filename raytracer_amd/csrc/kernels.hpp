@@ -39,7 +39,7 @@
 namespace rthip {
 
 #ifndef RT_QWAVES
-#define RT_QWAVES 7   // the global-memory variant is latency bound: one more wave per SIMD (72 VGPRs)
+#define RT_QWAVES 6   // (7, i.e. 72 registers, before the camera-ray batches and their packet walk came to these kernels)
 #endif
 #ifndef RT_MINWAVES
 #define RT_MINWAVES 6
@@ -79,6 +79,7 @@ struct RenderArgs {
 	uint32_t xchg_off, xchg_cap;  // kXchg: byte offset in LDS of the workgroup's exchange queues, and records per queue (a power of two)
 	int32_t xchg_pop_min;         // kXchg: take rays out of a queue only this many at a time (or when the wave has nothing else to do)
 	int32_t xchg_push_max;        // kXchg: an arm hands its rays over only when it holds at most this many lanes of the wave
+	int32_t packet;               // camera rays are traced 64 at a time as one packet per wave (kernels that make them in batches)
 };
 
 template <typename Real>
@@ -493,17 +494,30 @@ template <typename Real> struct Trav {
 	int32_t sp;       // in the stack's own unit, see StackLds / StackMem
 	Real best_t;
 	int32_t best_prim;  // index into prims, -1 = none
+#ifdef RT_SPEC
+	int32_t post;       // a leaf put aside while the lane walks on (0 = none)
+#endif
 };
 RT_FN void trav_begin(Trav<Real>& tv, int32_t stack_bottom) {
 	tv.cur = 0; tv.sp = stack_bottom; tv.best_t = Fp<Real>::max_finite(); tv.best_prim = -1;
+#ifdef RT_SPEC
+	tv.post = 0;
+#endif
+}
+RT_FN bool trav_has_leaf_aside(const Trav<Real>& tv) {
+#ifdef RT_SPEC
+	return tv.post != 0;
+#else
+	return false;
+#endif
 }
 struct Tally { uint32_t box, sphere, cube; };
 // Instrumented builds only: per code region, the lane-iterations executed (sum over active
 // lanes) and the wave-iterations issued (counted by the first active lane), whose ratio / 64
 // is the SIMD lane utilisation of that region.
-enum : int { kRegInner = 0, kRegSphere, kRegCube, kRegLeaf, kRegShade, kRegSky, kRegLambert, kRegMetal, kRegGlass, kRegStart, kRegTravRound, kRegXPush, kRegXPop, kRegXFull, kRegXSpin, kRegCount };
+enum : int { kRegInner = 0, kRegSphere, kRegCube, kRegLeaf, kRegShade, kRegSky, kRegLambert, kRegMetal, kRegGlass, kRegStart, kRegTravRound, kRegXPush, kRegXPop, kRegXFull, kRegXSpin, kRegPacket, kRegCount };
 // Instrumented builds also clock the phases of the wave's main loop (s_memtime, wave-uniform).
-enum : int { kPhShade = 0, kPhRegen, kPhFresh, kPhInner, kPhLeaf, kPhXchg, kPhTotal, kPhCount };
+enum : int { kPhShade = 0, kPhRegen, kPhFresh, kPhInner, kPhLeaf, kPhXchg, kPhPacket, kPhTotal, kPhCount };
 struct Regions { uint32_t lane[kRegCount], wave[kRegCount]; unsigned long long clk[kPhCount]; };
 template <bool kCount>
 __device__ __forceinline__ unsigned long long phase_begin() {
@@ -544,6 +558,12 @@ template <typename Real, typename Stack, bool kCount>
 __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, const Stack& stack, Tally& tally, Regions& rg,
                                            int32_t inner_exit = 0) {
 	const int32_t min_lanes = ((int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit + 15) >> 4;  // fewer than inner_exit sixteenths of those that entered
+#ifdef RT_SPEC
+	// A lane that arrives at a leaf while others still descend puts the leaf aside (tv.post) and walks on
+	// from its stack instead of waiting: the leaf is tested in the leaf step that follows, with whatever
+	// the lane reaches next.
+	if (tv.cur < 0 && tv.cur != kDone && tv.post == 0) { tv.post = tv.cur; trav_pop<Real>(tv, stack); }
+#endif
 	while (tv.cur >= 0) {
 		if ((int32_t)__popcll(__ballot(1)) < min_lanes) break;  // the rest wait at leaves: serve them first
 		region_tick<kCount>(rg, kRegInner);
@@ -564,6 +584,9 @@ __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& 
 		} else {
 			trav_pop<Real>(tv, stack);
 		}
+#ifdef RT_SPEC
+		if (tv.cur < 0 && tv.cur != kDone && tv.post == 0) { tv.post = tv.cur; trav_pop<Real>(tv, stack); }
+#endif
 	}
 }
 // The same descent over quantised nodes (f32 trees in global memory): two 16-byte loads per
@@ -638,8 +661,130 @@ __device__ __forceinline__ void leaf_tests(Trav<Real>& tv, const TravRay<Real>& 
 }
 template <typename Real, typename Stack, bool kCount>
 __device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, const Gate<Real>* gates, const Stack& stack, Tally& tally, Regions& rg) {
+#ifdef RT_SPEC
+	for (;;) {  // the leaf put aside, then the one the lane stands at
+		const bool at_leaf = tv.cur < 0 && tv.cur != kDone;
+		const int32_t leaf = tv.post != 0 ? tv.post : (at_leaf ? tv.cur : 0);
+		if (leaf == 0) break;
+		leaf_tests<Real, kCount>(tv, r, leaf, prims, gates, tally, rg);
+		if (tv.post != 0) tv.post = 0;
+		else trav_pop<Real>(tv, stack);
+	}
+#else
 	leaf_tests<Real, kCount>(tv, r, tv.cur, prims, gates, tally, rg);
 	trav_pop<Real>(tv, stack);
+#endif
+}
+
+// The 64 camera rays of one batch (an 8x8 tile, one sample) walked through the tree TOGETHER: one
+// wave-uniform node index, one stack for the wave (a register, entry k in lane k), every lane
+// tests its own ray against the two child boxes and the wave descends wherever any lane has to go,
+// nearer child first by majority.  Such rays differ by a pixel and a lens offset, so the union of
+// their walks is hardly longer than one walk, the node index is uniform (an LDS broadcast, scalar
+// control flow, no per-lane stack traffic) and all 64 lanes work in every step, where rays of
+// their own fill 40-70 % of the lanes in the same loops.  The closest hit of a ray does not depend
+// on the order its candidates are found in (ties go by rank), and the primitive tests decide
+// alone what counts, so a lane may test primitives its own walk would have culled: the result is
+// word for word the per-ray walk's.
+// A record read word by word through the pointer's own address space: with a pointer into the
+// constant address space and a wave-uniform index these are scalar loads.
+typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+template <typename T, typename Words>
+__device__ __forceinline__ T load_record(Words p) {
+	static_assert(sizeof(T) % 4 == 0, "records are made of 32-bit words");
+	uint32_t w[sizeof(T) / 4];
+#pragma unroll
+	for (uint32_t i = 0; i < sizeof(T) / 4; i++) w[i] = p[i];
+	T out;
+	__builtin_memcpy(&out, w, sizeof(T));
+	return out;
+}
+// leaf_tests for a packet: the leaf is the wave's, so every record is read once for the wave.
+template <typename Real, bool kCount, typename Words>
+__device__ __forceinline__ void packet_leaf_tests(Trav<Real>& tv, const TravRay<Real>& r, int32_t leaf, Words prims, Words gates, Tally& tally, Regions& rg) {
+	constexpr uint32_t kPrimWords = sizeof(Prim<Real>) / 4, kGateWords = sizeof(Gate<Real>) / 4, kRankWord = offsetof(Prim<Real>, rank) / 4;
+	region_tick<kCount>(rg, kRegLeaf);
+	const uint32_t code = ~(uint32_t)leaf;
+	const int32_t first = (int32_t)(code >> 6), ns = (int32_t)((code >> 3) & 7u), nc = (int32_t)(code & 7u);
+	auto better = [&](Real t, int32_t rank) {  // see leaf_tests
+		return t > Real(0.001) && (t < tv.best_t || (t == tv.best_t && tv.best_prim >= 0 && rank > (int32_t)prims[(uint32_t)tv.best_prim * kPrimWords + kRankWord]));
+	};
+	for (int32_t k = 0; k < ns; k++) {
+		const int32_t i = first + k;
+		const Prim<Real> pr = load_record<Prim<Real>>(prims + (uint32_t)i * kPrimWords);
+		Real t;
+		region_tick<kCount>(rg, kRegSphere);
+		if (kCount && kTally) tally.sphere++;
+		if (hit_sphere<Real>(pr, r, &t) && better(t, pr.rank)) {
+			const uint32_t n_gates = prim_gate_count(pr), first_gate = prim_gate_first(pr);
+			bool reachable = true;
+			for (uint32_t g = 0; g < n_gates; g++) {
+				const Gate<Real> gate = load_record<Gate<Real>>(gates + (first_gate + g) * kGateWords);
+				reachable = reachable && hit_box_reference<Real>(gate.box, r);
+			}
+			if (reachable) { tv.best_t = t; tv.best_prim = i; }
+		}
+	}
+	for (int32_t k = 0; k < nc; k++) {
+		const int32_t i = first + ns + k;
+		const Prim<Real> pr = load_record<Prim<Real>>(prims + (uint32_t)i * kPrimWords);
+		Real t;
+		region_tick<kCount>(rg, kRegCube);
+		if (kCount && kTally) tally.cube++;
+		if (hit_cube<Real>(pr, r, &t) && better(t, pr.rank)) { tv.best_t = t; tv.best_prim = i; }
+	}
+}
+template <typename Real, bool kCount, typename Words>
+__device__ __forceinline__ void packet_trace(Trav<Real>& pt, const TravRay<Real>& r, bool valid, Words nodes, Words prims, Words gates,
+                                             int32_t big_leaf, int32_t start, Tally& tally, Regions& rg) {
+	constexpr uint32_t kNodeWords = sizeof(Node<Real>) / 4;
+	const int32_t lane = (int32_t)(threadIdx.x & 63u);
+	trav_begin<Real>(pt, 0);
+	int32_t cur = 0;
+	if (big_leaf != 0) {
+		packet_leaf_tests<Real, kCount, Words>(pt, r, big_leaf, prims, gates, tally, rg);
+		cur = start;
+	}
+	if (start == kDone) cur = kDone;
+	int32_t sp = 0;
+	int wstack = 0;  // the wave's stack: entry k lives in lane k (tree depth <= 64, checked by the host)
+	for (;;) {
+		while (cur >= 0) {
+			region_tick<kCount>(rg, kRegPacket);
+			const Node<Real> n = load_record<Node<Real>>(nodes + (uint32_t)cur * kNodeWords);
+			Real el, er;
+			const bool hl = hit_box<Real>(n.box, r, pt.best_t, &el) && valid;
+			const bool hr = hit_box<Real>(n.box + 6, r, pt.best_t, &er) && valid;
+			const int32_t cl = __builtin_amdgcn_readfirstlane(n.child[0]), cr = __builtin_amdgcn_readfirstlane(n.child[1]);
+			if (kCount && kTally) tally.box += 2;
+			const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
+			if (ml != 0ull && mr != 0ull) {
+				const int32_t right_votes = (int32_t)__popcll(__ballot(hr && (!hl || er < el)));
+				const int32_t left_votes = (int32_t)__popcll(__ballot(hl && (!hr || !(er < el))));
+				const bool right_first = right_votes > left_votes;
+				wstack = lane == sp ? (right_first ? cl : cr) : wstack;
+				sp++;
+				cur = right_first ? cr : cl;
+			} else if (ml != 0ull) {
+				cur = cl;
+			} else if (mr != 0ull) {
+				cur = cr;
+			} else if (sp != 0) {
+				sp--;
+				cur = __builtin_amdgcn_readlane(wstack, sp);
+			} else {
+				cur = kDone;
+			}
+		}
+		if (cur == kDone) break;
+		packet_leaf_tests<Real, kCount, Words>(pt, r, cur, prims, gates, tally, rg);
+		if (sp != 0) {
+			sp--;
+			cur = __builtin_amdgcn_readlane(wstack, sp);
+		} else {
+			cur = kDone;
+		}
+	}
 }
 
 // BVH::trace, src/bvh.rs:130-142, with get_normal of src/shapes/sphere.rs:60-62 and
@@ -963,15 +1108,24 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	const uint32_t home_queue = blockIdx.x % kQueues;
 	bool queue_dry = false;
 	const uint32_t pool_size = 64u * A.chunk;
-	// f32 kernels with registers to spare make their camera rays in batches (see the regeneration step)
+	// f32 kernels make their camera rays in batches (see the regeneration step)
 #ifdef RT_NO_BATCH_REGEN
 	constexpr bool kBatchRegen = false;
 #else
-	constexpr bool kBatchRegen = std::is_same<Real, float>::value && !kQ;
+	constexpr bool kBatchRegen = std::is_same<Real, float>::value;
 #endif
 	V3<Real> sp_o = mk<Real>(0, 0, 0), sp_d = sp_o;
 	uint32_t sp_state = 0, sp_inc = 1, sp_accum = 0xFFFFFFFFu, sp_slot = 0;
 	uint32_t spare_pos = 0, spare_end = 0;
+	// ... and, where the launch asks for it, walks them through the tree as one packet (see packet_trace):
+	// the spares then carry their hit, and the lanes that take them start with shading.
+#ifdef RT_PACKET_LDS
+	constexpr bool kPacket = kBatchRegen;
+#else
+	constexpr bool kPacket = kBatchRegen && kLds == 0;  // scenes in LDS: measured slower (see packet_trace), and the code costs registers
+#endif
+	Real sp_t = 0;
+	int32_t sp_prim = -1;
 
 	for (;;) {
 		unsigned long long t_ph = phase_begin<kCount>();
@@ -1182,6 +1336,27 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 					}
 					pool_pos += n;
 					spare_pos = 0; spare_end = n;
+					if constexpr (kPacket) {
+						if (A.packet != 0) {
+							const unsigned long long t_pk = phase_begin<kCount>();
+							Trav<Real> pt;
+							const TravRay<Real> pr = prepare<Real>(RayT<Real>{sp_o, sp_d});
+							if constexpr (kLds != 0) {
+								typedef const uint32_t* Words;
+								packet_trace<Real, kCount, Words>(pt, pr, sp_accum != 0xFFFFFFFFu, reinterpret_cast<Words>(nodes), reinterpret_cast<Words>(prims), reinterpret_cast<Words>(gates),
+								                                  A.big_leaf, A.start, tally, rg);
+							} else {
+								// The scene is in global memory and is only read: through the constant address space a
+								// load from a wave-uniform address is a scalar load (one request per wave to the scalar
+								// cache instead of 64 lane requests to the vector L1, whose request rate is what bounds
+								// these scenes).  The packet walks the full nodes: nothing to decode.
+								packet_trace<Real, kCount, ConstWords>(pt, pr, sp_accum != 0xFFFFFFFFu, (ConstWords)A.scene, (ConstWords)(A.scene + A.prims_off), (ConstWords)(A.scene + A.gates_off),
+								                                       A.big_leaf, A.start, tally, rg);
+							}
+							sp_t = pt.best_t; sp_prim = pt.best_prim;
+							phase_end<kCount>(rg, kPhPacket, t_pk);
+						}
+					}
 				}
 				const uint32_t want = (uint32_t)__popcll(need), avail = spare_end - spare_pos;
 				const uint32_t take = want < avail ? want : avail;
@@ -1192,6 +1367,11 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				const Real dx = __shfl(sp_d.x, src, 64), dy = __shfl(sp_d.y, src, 64), dz = __shfl(sp_d.z, src, 64);
 				const uint32_t g_state = (uint32_t)__shfl((int)sp_state, src, 64), g_inc = (uint32_t)__shfl((int)sp_inc, src, 64);
 				const uint32_t g_accum = (uint32_t)__shfl((int)sp_accum, src, 64), g_slot = (uint32_t)__shfl((int)sp_slot, src, 64);
+				Real g_t = 0;
+				int32_t g_prim = -1;
+				if constexpr (kPacket) {
+					if (A.packet != 0) { g_t = __shfl(sp_t, src, 64); g_prim = __shfl(sp_prim, src, 64); }
+				}
 				if (mine && g_accum != 0xFFFFFFFFu) {
 					rng.state = g_state; rng.inc = g_inc;
 					accum_index = g_accum;
@@ -1203,6 +1383,9 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 					if (depth > 0) {
 						ray.o = mk<Real>(ox, oy, oz); ray.d = mk<Real>(dx, dy, dz);
 						state = kFresh;
+						if constexpr (kPacket) {
+							if (A.packet != 0) { tv.best_t = g_t; tv.best_prim = g_prim; state = kShade; }  // traced already: shading needs origin, direction and the hit
+						}
 					} else if (A.samples_out) {  // renderer.rs:10-12: depth <= 0 -> black
 						Real* so = A.samples_out + (size_t)sample_slot * 3;
 						so[0] = so[1] = so[2] = Real(0);
@@ -1291,7 +1474,11 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				else trav_inner<Real, Stack, kCount>(tv, ray, nodes, stack, tally, rg, A.inner_exit);
 				phase_end<kCount>(rg, kPhInner, t_ph);
 				t_ph = phase_begin<kCount>();
+#ifdef RT_SPEC
+				if (tv.post != 0 || (tv.cur < 0 && tv.cur != kDone)) trav_leaf<Real, Stack, kCount>(tv, ray, prims, gates, stack, tally, rg);
+#else
 				if (tv.cur < 0 && tv.cur != kDone) trav_leaf<Real, Stack, kCount>(tv, ray, prims, gates, stack, tally, rg);
+#endif
 				phase_end<kCount>(rg, kPhLeaf, t_ph);
 				if (tv.cur == kDone) state = kShade;
 			}
@@ -1338,7 +1525,7 @@ __global__ __launch_bounds__(kProbeBlock) void probe_kernel(ProbeArgs<Real> A) {
 	Regions rg{};
 	while (tv.cur != kDone) {
 		trav_inner<Real, Stack, false>(tv, ray, nodes, stack, tally, rg);
-		if (tv.cur != kDone) trav_leaf<Real, Stack, false>(tv, ray, prims, gates, stack, tally, rg);
+		if (tv.cur != kDone || trav_has_leaf_aside<Real>(tv)) trav_leaf<Real, Stack, false>(tv, ray, prims, gates, stack, tally, rg);
 	}
 	if (tv.best_prim < 0) {
 		A.id[i] = -1; A.t[i] = 0.0; A.front[i] = 0;

@@ -35,18 +35,21 @@ def test_variants_and_trees_agree(rt, scene, cam):
         assert (words != ref_words).mean() < 1e-3, (tree, variant)
 
 
-@pytest.mark.parametrize("scene,cam,sky", [("default", CAM, 0), ("sample", CAM, 0), ("glass", CAM, 0), ("wallpaper", CAM, 1), ("synthetic:120000", CAM5, 0)])
+@pytest.mark.parametrize("scene,cam,sky", [("default", CAM, 0), ("sample", CAM, 0), ("glass", CAM, 0), ("wallpaper", CAM, 1), ("synthetic:5000", CAM5, 0),
+                                           ("synthetic:120000", CAM5, 0)])
 def test_launch_options_change_no_word(rt, scene, cam, sky):
     """The launch-side experiments and shortcuts (rays regrouped by shading arm through LDS queues, with
     small and with large queues; traversal stacks in global memory; both at once; a one-leaf scene walked
-    from its root instead of tested at ray start; other workgroup sizes) render the same accumulation
+    from its root instead of tested at ray start; other workgroup sizes; for scenes in global memory the
+    camera rays walked one by one instead of 64 at a time as a packet, on full and on quantised nodes) render the same accumulation
     words as the defaults: paths are deterministic and accumulation is integer, so which lane, wave or
     workgroup carries a ray, and where its stack lives, cannot show in the image."""
     sc = rt.Scene.generate(scene)
     w, h = 640, 360
     ref = None
     for opts in ({}, {"xchg": 1}, {"xchg": 1, "xchg_cap": 64, "xchg_pop_min": 8}, {"xchg": 1, "xchg_push_max": 6, "xchg_pop_min": 40},
-                 {"stack_mem": 1}, {"xchg": 1, "stack_mem": 1}, {"root_leaf": 0}, {"threads": 256}, {"threads": 512}, {"chunk": 3}):
+                 {"stack_mem": 1}, {"xchg": 1, "stack_mem": 1}, {"root_leaf": 0}, {"threads": 256}, {"threads": 512}, {"chunk": 3}, {"packet": 0}, {"packet": 0, "qnodes": 0}, {"qnodes": 0},
+                 {"scene_lds": 0}, {"scene_lds": 0, "packet": 0}):
         r = rt.Renderer(sc, rt.Camera(*cam[:5], w, h), seed=3, max_depth=12, sky_mode=sky, options=opts)
         r.accumulate(16, spp_begin=0)       # 3.7 M paths: long enough for the queues to be used (short launches leave them out) and served
         _, n = r.accum_buffer()

@@ -1,6 +1,6 @@
 """A/B of option sets (rthip_set_option names; the old per-variable sweeps in one tool) on bench
 workloads, one process:
-  python tools/ab_opts.py [--wl cfg2,cfg3,cfg5] [--spp N] "sah_cprim=0.4,mats_lds=0" "threads=768" ...   ('-' = defaults)"""
+  python tools/ab_opts.py [--wl cfg2,cfg3,cfg5] [--spp N] [--size WxH] "sah_cprim=0.4,mats_lds=0" "threads=768" ...   ('-' = defaults)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
@@ -15,6 +15,9 @@ if args and args[0] == "--wl":
 spp_override = None
 if args and args[0] == "--spp":
     spp_override, args = int(args[1]), args[2:]
+size = (1920, 1080)
+if args and args[0] == "--size":
+    size, args = tuple(int(v) for v in args[1].split("x")), args[2:]
 sets = args or ["-"]
 for name in which:
     scene, depth, cam, spp = WL.get(name, (name, 50, CAM5, 8))
@@ -22,7 +25,7 @@ for name in which:
     sc = rt.Scene.generate(scene)
     for spec in sets:
         opts = {} if spec == "-" else {k: float(v) for k, v in (kv.split("=") for kv in spec.split(","))}
-        r = rt.Renderer(sc, rt.Camera(*cam, 1920, 1080), max_depth=depth, seed=1, options=opts)
+        r = rt.Renderer(sc, rt.Camera(*cam, *size), max_depth=depth, seed=1, options=opts)
         best = 0
         for _ in range(4):
             r.reset_accumulation(); r.accumulate(spp, spp_begin=0)
