@@ -184,6 +184,7 @@ struct Rng {
 		state = b;
 		inc = (mix32(b + a + 0xC2B2AE35u) << 1) | 1u;
 	}
+	__device__ __forceinline__ void skip() { state = state * 747796405u + inc; }  // a draw whose value nobody looks at
 	__device__ __forceinline__ uint32_t next() {
 		uint32_t old = state;
 		state = old * 747796405u + inc;
@@ -260,18 +261,35 @@ template <typename Real> struct TravRay {
 };
 // `frame` (f32 traversal over quantised nodes) moves the box-test operands into grid units; the
 // primitive tests keep using o, d, inv.
-RT_FN TravRay<Real> prepare(RayT<Real> r, const QFrame* frame = nullptr) {
-	TravRay<Real> t;
-	t.o = r.o; t.d = r.d;
-	t.inv = mk<Real>(Fp<Real>::rcp(r.d.x), Fp<Real>::rcp(r.d.y), Fp<Real>::rcp(r.d.z));
+RT_FN V3<Real> ray_inv(V3<Real> d) {
+	V3<Real> inv = mk<Real>(Fp<Real>::rcp(d.x), Fp<Real>::rcp(d.y), Fp<Real>::rcp(d.z));
 	if constexpr (std::is_same<Real, float>::value) {
 		// A zero (or flushed) direction component gives inv = inf and plane * inf - o * inf = NaN for
 		// every plane; a huge finite stand-in keeps the sign of (plane - o), which is all that axis
 		// contributes for such a ray.
-		t.inv.x = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(t.inv.x), 0x1p64f), t.inv.x);
-		t.inv.y = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(t.inv.y), 0x1p64f), t.inv.y);
-		t.inv.z = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(t.inv.z), 0x1p64f), t.inv.z);
+		inv.x = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(inv.x), 0x1p64f), inv.x);
+		inv.y = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(inv.y), 0x1p64f), inv.y);
+		inv.z = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(inv.z), 0x1p64f), inv.z);
 	}
+	return inv;
+}
+// Kernels that walk quantised nodes do not keep inv and rcp_a between the primitive tests (the box
+// test there works on qscale, and registers are what limits those kernels): the leaf step makes
+// them again, by the formulas of prepare(), so the primitive tests see the same numbers.
+template <bool kLean, typename Real>
+__device__ __forceinline__ TravRay<Real> leaf_ray(const TravRay<Real>& r) {
+	if constexpr (!kLean) return r;
+	else {
+		TravRay<Real> t = r;
+		t.inv = ray_inv<Real>(r.d);
+		t.rcp_a = Fp<Real>::rcp(dot(r.d, r.d));
+		return t;
+	}
+}
+RT_FN TravRay<Real> prepare(RayT<Real> r, const QFrame* frame = nullptr) {
+	TravRay<Real> t;
+	t.o = r.o; t.d = r.d;
+	t.inv = ray_inv<Real>(r.d);
 	V3<Real> box_o = r.o;
 	t.qscale = t.inv;
 	Real reach = Real(0);  // largest |plane| the box test multiplies by inv, beside the origin
@@ -1117,6 +1135,11 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	V3<Real> sp_o = mk<Real>(0, 0, 0), sp_d = sp_o;
 	uint32_t sp_state = 0, sp_inc = 1, sp_accum = 0xFFFFFFFFu, sp_slot = 0;
 	uint32_t spare_pos = 0, spare_end = 0;
+	// Kernels of scenes in global memory are short of registers: their spares keep origin, direction and hit
+	// only, and the lane that takes one works out pixel, slots and random stream again from the batch's
+	// place in its work item (the stream after the camera's draws, which are the same number for every ray).
+	constexpr bool kLeanSpares = kLds == 0;
+	uint32_t sp_item = 0, sp_base = 0;
 	// ... and, where the launch asks for it, walks them through the tree as one packet (see packet_trace):
 	// the spares then carry their hit, and the lanes that take them start with shading.
 #ifdef RT_PACKET_LDS
@@ -1323,15 +1346,20 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				if (spare_pos == spare_end) {
 					const uint32_t n = min(64u, pool_end - pool_pos);
 					sp_accum = 0xFFFFFFFFu;  // no path: outside the image, or a sample beyond spp_count
+					sp_item = item; sp_base = pool_pos;
+					bool sp_valid = false;
 					PathId id;
 					if (lane < n && decode_path(item, pool_pos + lane, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order)) {
 						Rng g;
 						g.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
 						const RayT<Real> r = camera_ray<Real>(A.cam, (Real)id.px, (Real)id.py, g, true);
 						sp_o = r.o; sp_d = r.d;
-						sp_state = g.state; sp_inc = g.inc;
-						sp_accum = id.accum_index;
-						sp_slot = (id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px;
+						sp_valid = true;
+						if constexpr (!kLeanSpares) {
+							sp_state = g.state; sp_inc = g.inc;
+							sp_accum = id.accum_index;
+							sp_slot = (id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px;
+						}
 						region_tick<kCount>(rg, kRegStart);
 					}
 					pool_pos += n;
@@ -1343,14 +1371,14 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 							const TravRay<Real> pr = prepare<Real>(RayT<Real>{sp_o, sp_d});
 							if constexpr (kLds != 0) {
 								typedef const uint32_t* Words;
-								packet_trace<Real, kCount, Words>(pt, pr, sp_accum != 0xFFFFFFFFu, reinterpret_cast<Words>(nodes), reinterpret_cast<Words>(prims), reinterpret_cast<Words>(gates),
+								packet_trace<Real, kCount, Words>(pt, pr, sp_valid, reinterpret_cast<Words>(nodes), reinterpret_cast<Words>(prims), reinterpret_cast<Words>(gates),
 								                                  A.big_leaf, A.start, tally, rg);
 							} else {
 								// The scene is in global memory and is only read: through the constant address space a
 								// load from a wave-uniform address is a scalar load (one request per wave to the scalar
 								// cache instead of 64 lane requests to the vector L1, whose request rate is what bounds
 								// these scenes).  The packet walks the full nodes: nothing to decode.
-								packet_trace<Real, kCount, ConstWords>(pt, pr, sp_accum != 0xFFFFFFFFu, (ConstWords)A.scene, (ConstWords)(A.scene + A.prims_off), (ConstWords)(A.scene + A.gates_off),
+								packet_trace<Real, kCount, ConstWords>(pt, pr, sp_valid, (ConstWords)A.scene, (ConstWords)(A.scene + A.prims_off), (ConstWords)(A.scene + A.gates_off),
 								                                       A.big_leaf, A.start, tally, rg);
 							}
 							sp_t = pt.best_t; sp_prim = pt.best_prim;
@@ -1365,8 +1393,22 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				const int src = mine ? (int)(spare_pos + rk) : (int)lane;  // every lane takes part in the exchange
 				const Real ox = __shfl(sp_o.x, src, 64), oy = __shfl(sp_o.y, src, 64), oz = __shfl(sp_o.z, src, 64);
 				const Real dx = __shfl(sp_d.x, src, 64), dy = __shfl(sp_d.y, src, 64), dz = __shfl(sp_d.z, src, 64);
-				const uint32_t g_state = (uint32_t)__shfl((int)sp_state, src, 64), g_inc = (uint32_t)__shfl((int)sp_inc, src, 64);
-				const uint32_t g_accum = (uint32_t)__shfl((int)sp_accum, src, 64), g_slot = (uint32_t)__shfl((int)sp_slot, src, 64);
+				uint32_t g_state = 0, g_inc = 1, g_accum = 0xFFFFFFFFu, g_slot = 0;
+				if constexpr (!kLeanSpares) {
+					g_state = (uint32_t)__shfl((int)sp_state, src, 64); g_inc = (uint32_t)__shfl((int)sp_inc, src, 64);
+					g_accum = (uint32_t)__shfl((int)sp_accum, src, 64); g_slot = (uint32_t)__shfl((int)sp_slot, src, 64);
+				} else if (mine) {
+					PathId id;
+					if (decode_path(sp_item, sp_base + (uint32_t)src, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order)) {
+						Rng g;
+						g.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
+						const int draws = A.cam.defocus_angle > Real(0) ? 4 : 2;  // camera_ray: two for the jitter, two for the lens
+						for (int k = 0; k < draws; k++) g.skip();
+						g_state = g.state; g_inc = g.inc;
+						g_accum = id.accum_index;
+						g_slot = (id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px;
+					}
+				}
 				Real g_t = 0;
 				int32_t g_prim = -1;
 				if constexpr (kPacket) {
@@ -1441,7 +1483,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 			// that start a ray do so together instead of one by one in the leaf loops, and the tree
 			// below is walked with their hit distance already known.
 			if (A.big_leaf != 0) {
-				leaf_tests<Real, kCount>(tv, ray, A.big_leaf, prims, gates, tally, rg);
+				leaf_tests<Real, kCount>(tv, leaf_ray<kQ, Real>(ray), A.big_leaf, prims, gates, tally, rg);
 				tv.cur = A.start;
 			}
 			state = A.start == kDone ? kShade : kTraverse;  // (a scene that is one leaf: nothing to walk)
@@ -1475,9 +1517,9 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				phase_end<kCount>(rg, kPhInner, t_ph);
 				t_ph = phase_begin<kCount>();
 #ifdef RT_SPEC
-				if (tv.post != 0 || (tv.cur < 0 && tv.cur != kDone)) trav_leaf<Real, Stack, kCount>(tv, ray, prims, gates, stack, tally, rg);
+				if (tv.post != 0 || (tv.cur < 0 && tv.cur != kDone)) trav_leaf<Real, Stack, kCount>(tv, leaf_ray<kQ, Real>(ray), prims, gates, stack, tally, rg);
 #else
-				if (tv.cur < 0 && tv.cur != kDone) trav_leaf<Real, Stack, kCount>(tv, ray, prims, gates, stack, tally, rg);
+				if (tv.cur < 0 && tv.cur != kDone) trav_leaf<Real, Stack, kCount>(tv, leaf_ray<kQ, Real>(ray), prims, gates, stack, tally, rg);
 #endif
 				phase_end<kCount>(rg, kPhLeaf, t_ph);
 				if (tv.cur == kDone) state = kShade;
