@@ -463,7 +463,8 @@ def main():
                                        "kernel": "render_kernel<float> (scene in global memory, quantised nodes)",
                                        "note": "achieved = measured L2-miss bytes (FETCH_SIZE + WRITE_SIZE per path x paths) over kernel time; "
                                                "requested = node visits x node size + primitive tests x 32 + hits x 16 on the tree the kernel walks, "
-                                               "served mostly by L1/L2 (the kernel is bound by the L1's request rate, not by HBM)"}
+                                               "(camera rays walk it as wave packets whose node reads are one scalar load per wave: they are counted per lane here), "
+                                               "served mostly by L1/L2 (the kernel waits on dependent loads and issues VALU work, it is not bound by HBM)"}
             else:
                 gbs = hbm_alg / secs / 1e9
                 out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic,
