@@ -499,6 +499,7 @@ template <typename Real>
 int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, unsigned long long* accum, Real* samples_out, char* control = nullptr,
                        bool frugal = false, bool timed = true) {
 	if (!control) control = c->d_control;
+	if (samples_out && std::is_same<Real, float>::value) count = true;   // only the instrumented f32 kernels write per-sample radiance
 	Plan plan;
 	int32_t rc = make_plan(c, p, count, &plan, false, frugal);
 	if (rc != RTHIP_OK) return rc;

@@ -1084,6 +1084,9 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 		gates = reinterpret_cast<const Gate<Real>*>(A.scene + A.gates_off);
 	}
 	const uint32_t lane = threadIdx.x & 63u;
+	// Per-sample radiance (samples_out: parity tests and probes) is written by the f64 kernels and by the
+	// instrumented f32 ones; the f32 production kernels do not carry a path's sample slot along.
+	constexpr bool kSamples = kCount || !std::is_same<Real, float>::value;
 	// the wave's accumulation tile (kAccLds): [channel][64 px] words behind the stacks and the scene copy
 	unsigned long long* acc_tile = nullptr;
 	unsigned long long* acc_dst = A.accum;  // where the tile belongs in the accumulation buffer
@@ -1110,7 +1113,8 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 	uint32_t accum_index = 0, sample_slot = 0;
 	Tally tally{0, 0, 0};
 	Regions rg{};
-	uint32_t n_rays = 0, n_paths = 0;
+	uint32_t n_paths = 0;                // per lane: kernels that start their paths on demand
+	uint32_t w_rays = 0, w_paths = 0;    // per wave (scalar registers): rays shaded, paths started in batches
 	tv.cur = kDone; tv.sp = 0; tv.best_t = 0; tv.best_prim = -1;
 	rng.state = 0; rng.inc = 1;
 	T = L = mk<Real>(0, 0, 0);
@@ -1147,8 +1151,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 #else
 	constexpr bool kPacket = kBatchRegen && kLds == 0;  // scenes in LDS: measured slower (see packet_trace), and the code costs registers
 #endif
-	Real sp_t = 0;
-	int32_t sp_prim = -1;
+	uint32_t sp_fh_state = 0, sp_fh_hit = 0;
 
 	for (;;) {
 		unsigned long long t_ph = phase_begin<kCount>();
@@ -1260,7 +1263,9 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 		phase_end<kCount>(rg, kPhXchg, t_ph);
 		t_ph = phase_begin<kCount>();
 		// ---- shading ---------------------------------------------------------------------
-		const bool any_shade = __ballot(state == kShade) != 0ull;
+		const unsigned long long m_shade = __ballot(state == kShade);
+		const bool any_shade = m_shade != 0ull;
+		w_rays += (uint32_t)__popcll(m_shade);
 		if (state == kShade) {
 			region_tick<kCount>(rg, kRegShade);
 			if constexpr (kCount && kTally) {  // which arm of the shading code each lane takes: the arms run one after the other
@@ -1272,13 +1277,12 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 					else region_tick<kCount>(rg, kRegLambert);
 				}
 			}
-			n_rays++;
 			RayT<Real> next;
 			if (shade_ray<Real>(ray, tv.best_t, tv.best_prim, prims, mats, A.sky_mode, rng, T, L, depth, &next)) {
 				ray.o = next.o; ray.d = next.d;
 				state = kFresh;
 			} else {
-				if (A.samples_out) {
+				if (kSamples && A.samples_out) {
 					Real* so = A.samples_out + (size_t)sample_slot * 3;
 					so[0] = L.x; so[1] = L.y; so[2] = L.z;
 				}
@@ -1343,19 +1347,30 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				// "spares"); idle lanes then pick theirs up from whichever lane holds it (ds_bpermute).
 				// Making them on demand ran ray generation, a sixth of the kernel's arithmetic, on the
 				// 16-30 lanes that happened to be idle.
+				// Where the launch asks for it (kPacket), a batch goes further before it is handed out: its rays
+				// walk the tree together (packet_trace) and are shaded together, all 64 lanes at work; paths that
+				// end with their first ray (sky, absorbed, depth limit) add their sample right there, and the
+				// spares that remain are the *second* rays of their paths, moved up so that they stand in a row.
+#ifdef RT_PACKET_ONLY
+				constexpr bool kFirstOnly = kPacket;
+#else
+				constexpr bool kFirstOnly = false;
+#endif
+				const bool first_hit = kPacket && (kFirstOnly || (A.packet != 0 && A.max_depth > 0));
 				if (spare_pos == spare_end) {
 					const uint32_t n = min(64u, pool_end - pool_pos);
 					sp_accum = 0xFFFFFFFFu;  // no path: outside the image, or a sample beyond spp_count
 					sp_item = item; sp_base = pool_pos;
 					bool sp_valid = false;
 					PathId id;
+					Rng g;
+					g.state = 0; g.inc = 1;
 					if (lane < n && decode_path(item, pool_pos + lane, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order)) {
-						Rng g;
 						g.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
 						const RayT<Real> r = camera_ray<Real>(A.cam, (Real)id.px, (Real)id.py, g, true);
 						sp_o = r.o; sp_d = r.d;
 						sp_valid = true;
-						if constexpr (!kLeanSpares) {
+						if constexpr (!kLeanSpares && !kFirstOnly) {
 							sp_state = g.state; sp_inc = g.inc;
 							sp_accum = id.accum_index;
 							sp_slot = (id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px;
@@ -1365,7 +1380,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 					pool_pos += n;
 					spare_pos = 0; spare_end = n;
 					if constexpr (kPacket) {
-						if (A.packet != 0) {
+						if (first_hit) {
 							const unsigned long long t_pk = phase_begin<kCount>();
 							Trav<Real> pt;
 							const TravRay<Real> pr = prepare<Real>(RayT<Real>{sp_o, sp_d});
@@ -1381,7 +1396,51 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 								packet_trace<Real, kCount, ConstWords>(pt, pr, sp_valid, (ConstWords)A.scene, (ConstWords)(A.scene + A.prims_off), (ConstWords)(A.scene + A.gates_off),
 								                                       A.big_leaf, A.start, tally, rg);
 							}
-							sp_t = pt.best_t; sp_prim = pt.best_prim;
+							bool live = false;
+							{
+								const uint32_t n_valid = (uint32_t)__popcll(__ballot(sp_valid));
+								w_paths += n_valid; w_rays += n_valid;
+							}
+							if (sp_valid) {
+								// (pixel and random stream are worked out again here rather than kept in registers through the walk)
+								decode_path(sp_item, sp_base + lane, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order);
+								g.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
+								const int draws = A.cam.defocus_angle > Real(0) ? 4 : 2;  // camera_ray: two for the jitter, two for the lens
+								for (int k = 0; k < draws; k++) g.skip();
+								V3<Real> T1 = mk<Real>(1, 1, 1), L1 = mk<Real>(0, 0, 0);
+								int32_t depth1 = A.max_depth;
+								RayT<Real> next;
+								if (shade_ray<Real>(pr, pt.best_t, pt.best_prim, prims, mats, A.sky_mode, g, T1, L1, depth1, &next)) {
+									live = true;
+									sp_o = next.o; sp_d = next.d;   // T and L of a path after one hit follow from the material: the lane that takes the ray reads them there
+								} else {
+									if (kSamples && A.samples_out) {
+										Real* so = A.samples_out + ((size_t)(id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px) * 3;
+										so[0] = L1.x; so[1] = L1.y; so[2] = L1.z;
+									}
+									if constexpr (kAccLds) {
+										unsigned long long* acc = acc_tile + (id.accum_index & 63u);
+										atomicAdd(acc, to_fixed<Real>(Fp<Real>::sqrt(L1.x)));
+										atomicAdd(acc + kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L1.y)));
+										atomicAdd(acc + 2 * kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L1.z)));
+									} else {
+										accumulate_sample<Real>(A.accum, id.accum_index, L1);
+									}
+								}
+							}
+							// the rays that go on move to the front (the others behind them): ds_permute sends, lane by lane
+							const unsigned long long m_live = __ballot(live);
+							const uint32_t n_live = (uint32_t)__popcll(m_live);
+							const int to = (int)(live ? lane_rank(m_live) : n_live + lane_rank(~m_live)) * 4;
+							sp_o.x = __builtin_bit_cast(Real, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, sp_o.x)));
+							sp_o.y = __builtin_bit_cast(Real, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, sp_o.y)));
+							sp_o.z = __builtin_bit_cast(Real, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, sp_o.z)));
+							sp_d.x = __builtin_bit_cast(Real, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, sp_d.x)));
+							sp_d.y = __builtin_bit_cast(Real, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, sp_d.y)));
+							sp_d.z = __builtin_bit_cast(Real, __builtin_amdgcn_ds_permute(to, __builtin_bit_cast(int, sp_d.z)));
+							sp_fh_state = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)g.state);
+							sp_fh_hit = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)(((uint32_t)pt.best_prim << 6) | lane));   // the primitive hit, and whose pixel this was
+							spare_end = n_live;
 							phase_end<kCount>(rg, kPhPacket, t_pk);
 						}
 					}
@@ -1393,6 +1452,32 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				const int src = mine ? (int)(spare_pos + rk) : (int)lane;  // every lane takes part in the exchange
 				const Real ox = __shfl(sp_o.x, src, 64), oy = __shfl(sp_o.y, src, 64), oz = __shfl(sp_o.z, src, 64);
 				const Real dx = __shfl(sp_d.x, src, 64), dy = __shfl(sp_d.y, src, 64), dz = __shfl(sp_d.z, src, 64);
+				bool taken_first_hit = false;
+				if constexpr (kPacket) {
+					if (first_hit) {
+						taken_first_hit = true;
+						const uint32_t st = (uint32_t)__shfl((int)sp_fh_state, src, 64), hit = (uint32_t)__shfl((int)sp_fh_hit, src, 64);
+						if (mine) {
+							PathId id;
+							decode_path(sp_item, sp_base + (hit & 63u), A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order);
+							rng.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);   // for the stream's increment
+							rng.state = st;
+							accum_index = id.accum_index;
+							sample_slot = (id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px;
+							// shade_ray on a path's first hit leaves T = attenuation and L = emission exactly (1 * x and 0 + x)
+							const int32_t prim = (int32_t)(hit >> 6);
+							const Mat<Real> mat = mats[prim];
+							const int material = (prims[prim].id >> kMatShift) & 3;
+							T = material == RTHIP_DIELECTRIC ? mk<Real>(1, 1, 1) : ld3(mat.albedo);
+							L = material == RTHIP_LAMBERTIAN ? ld3(mat.albedo) * mat.param : mk<Real>(0, 0, 0);
+							depth = A.max_depth - 1;
+							ray.o = mk<Real>(ox, oy, oz); ray.d = mk<Real>(dx, dy, dz);
+							state = kFresh;
+						}
+					}
+				}
+				if constexpr (!kFirstOnly) {
+				if (!taken_first_hit) {
 				uint32_t g_state = 0, g_inc = 1, g_accum = 0xFFFFFFFFu, g_slot = 0;
 				if constexpr (!kLeanSpares) {
 					g_state = (uint32_t)__shfl((int)sp_state, src, 64); g_inc = (uint32_t)__shfl((int)sp_inc, src, 64);
@@ -1409,11 +1494,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 						g_slot = (id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px;
 					}
 				}
-				Real g_t = 0;
-				int32_t g_prim = -1;
-				if constexpr (kPacket) {
-					if (A.packet != 0) { g_t = __shfl(sp_t, src, 64); g_prim = __shfl(sp_prim, src, 64); }
-				}
+				w_paths += (uint32_t)__popcll(__ballot(mine && g_accum != 0xFFFFFFFFu));
 				if (mine && g_accum != 0xFFFFFFFFu) {
 					rng.state = g_state; rng.inc = g_inc;
 					accum_index = g_accum;
@@ -1421,17 +1502,15 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 					T = mk<Real>(1, 1, 1);
 					L = mk<Real>(0, 0, 0);
 					depth = A.max_depth;
-					n_paths++;
 					if (depth > 0) {
 						ray.o = mk<Real>(ox, oy, oz); ray.d = mk<Real>(dx, dy, dz);
 						state = kFresh;
-						if constexpr (kPacket) {
-							if (A.packet != 0) { tv.best_t = g_t; tv.best_prim = g_prim; state = kShade; }  // traced already: shading needs origin, direction and the hit
-						}
-					} else if (A.samples_out) {  // renderer.rs:10-12: depth <= 0 -> black
+					} else if (kSamples && A.samples_out) {  // renderer.rs:10-12: depth <= 0 -> black
 						Real* so = A.samples_out + (size_t)sample_slot * 3;
 						so[0] = so[1] = so[2] = Real(0);
 					}
+				}
+				}
 				}
 				spare_pos += take;
 			} else {
@@ -1455,7 +1534,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 						if (depth > 0) {
 							ray.o = r.o; ray.d = r.d;
 							state = kFresh;
-						} else if (A.samples_out) {  // renderer.rs:10-12: depth <= 0 -> black
+						} else if (kSamples && A.samples_out) {  // renderer.rs:10-12: depth <= 0 -> black
 							Real* so = A.samples_out + (size_t)sample_slot * 3;
 							so[0] = so[1] = so[2] = Real(0);
 						}
@@ -1530,7 +1609,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 
 	flush_tile();
 	// ---- statistics: one atomic per wave ------------------------------------------------
-	unsigned long long v[5 + 2 * kRegCount + kPhCount] = {n_paths, n_rays, tally.box, tally.sphere, tally.cube};
+	unsigned long long v[5 + 2 * kRegCount + kPhCount] = {n_paths + (lane == 0 ? w_paths : 0u), lane == 0 ? w_rays : 0u, tally.box, tally.sphere, tally.cube};
 	if constexpr (kCount) {
 		rg.clk[kPhTotal] = __builtin_amdgcn_s_memtime() - t_kernel;
 		for (int k = 0; k < kRegCount; k++) { v[5 + k] = rg.lane[k]; v[5 + kRegCount + k] = rg.wave[k]; }

@@ -63,3 +63,36 @@ def test_launch_options_change_no_word(rt, scene, cam, sky):
             continue
         assert s["rays"] == ref_rays, opts
         assert np.array_equal(words, ref), opts
+
+
+@pytest.mark.parametrize("scene,cam", [("default", CAM), ("synthetic:5000", CAM5)])
+def test_depth_limits_with_and_without_packets(rt, scene, cam):
+    """Depth limits 0, 1 and 2 (src/renderer.rs:10-12: depth <= 0 is black): a path then ends at or right
+    after its first ray, which is the part that batches of camera rays handle on their own when they walk
+    the tree as packets.  Same words with packets and without; path and ray counts as the limits say; the
+    f32 kernels that write per-sample radiance (the instrumented ones) agree with the accumulated image."""
+    sc = rt.Scene.generate(scene)
+    w, h, spp = 320, 184, 4
+    for depth in (0, 1, 2):
+        got = {}
+        for packet in (1, 0):
+            r = rt.Renderer(sc, rt.Camera(*cam[:5], w, h), seed=5, max_depth=depth, options={"packet": packet})
+            r.accumulate(spp, spp_begin=0)
+            words = r.read_accum()
+            s = r.stats()
+            assert s["paths"] == w * h * spp, (depth, packet)
+            assert s["rays"] == (0 if depth == 0 else s["paths"] if depth == 1 else s["rays"]), (depth, packet)
+            if depth == 2:
+                assert s["paths"] < s["rays"] <= 2 * s["paths"]
+            smp = r.render_samples(spp)                      # [spp][H][W][3] linear radiance, f32
+            r.close()
+            got[packet] = (words, s["rays"], smp)
+        assert np.array_equal(got[1][0], got[0][0]), depth
+        assert got[1][1] == got[0][1], depth
+        assert np.array_equal(got[1][2], got[0][2]), depth
+        if depth == 0:
+            assert not got[1][0].any() and not got[1][2].any()
+        else:
+            assert got[1][0].any()
+        # the image is the sum over samples of sqrt(radiance) (f32 square root: an ulp; fixed point: 2^-36 per sample)
+        assert np.allclose(got[1][0], np.sqrt(np.clip(got[1][2], 0.0, 65536.0)).sum(axis=0), rtol=2e-6, atol=1e-6), depth
