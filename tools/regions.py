@@ -6,7 +6,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
-WL = {"cfg2": ("default", 10), "cfg3": ("sample", 50), "cfg4": ("wallpaper", 10)}
+WL = {"cfg2": ("default", 10), "cfg3": ("sample", 50), "cfg4": ("wallpaper", 10), "cfg5": ("synthetic:1000000", 50)}
+CAM5 = ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0)
 CAM4 = ((0.0, 0.0, 0.0), rt.get_camera_rotation(-90.0, 0.0), 90.0, 10.0, 0.6)
 args = sys.argv[1:]
 which, spp = ["cfg2", "cfg3"], 16
@@ -25,7 +26,7 @@ for name in which:
         if os.path.exists(path): os.remove(path)
         os.environ["RTHIP_REGION_DUMP"] = path
         opts = {} if spec == "-" else {k: float(v) for k, v in (kv.split("=") for kv in spec.split(","))}
-        cam = rt.Camera(*CAM4, 3840, 2160) if name == "cfg4" else rt.Camera(*CAM, 1920, 1080)
+        cam = rt.Camera(*CAM4, 3840, 2160) if name == "cfg4" else rt.Camera(*CAM5, 3840, 2160) if name == "cfg5" else rt.Camera(*CAM, 1920, 1080)
         r = rt.Renderer(sc, cam, max_depth=depth, seed=1, options=opts, sky_mode=1 if name == "cfg4" else 0)
         r.accumulate(spp)
         s = r.stats()
