@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 #ifdef RT_PACKET_LDS
 	constexpr bool kPacket = kBatchRegen;
 #else
-	constexpr bool kPacket = kBatchRegen && kLds == 0;  // scenes in LDS: measured slower (see packet_trace), and the code costs registers
+	constexpr bool kPacket = kBatchRegen && kLds == 0;  // scenes in LDS: measured slower (see packet_trace; the three-object scene as well: 83 against 87 Gpaths/s), and the code costs registers
 #endif
 	uint32_t sp_fh_state = 0, sp_fh_hit = 0;
 

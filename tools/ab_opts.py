@@ -7,7 +7,8 @@ import raytracer_amd as rt
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 CAM5 = ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0)
 # any other name is taken as a scene of rt.Scene.generate (e.g. synthetic:1500) under the cfg5 camera
-WL = {"cfg2": ("default", 10, CAM, 32), "cfg3": ("sample", 50, CAM, 32), "cfg5": ("synthetic:1000000", 50, CAM5, 8)}
+CAM4 = ((0.0, 0.0, 0.0), rt.get_camera_rotation(-90.0, 0.0), 90.0, 10.0, 0.6)   # cfg4: the wallpaper view (pass --size 3840x2160 for its own frame)
+WL = {"cfg4": ("wallpaper", 10, CAM4, 32), "cfg2": ("default", 10, CAM, 32), "cfg3": ("sample", 50, CAM, 32), "cfg5": ("synthetic:1000000", 50, CAM5, 8)}
 args = sys.argv[1:]
 which = ["cfg2", "cfg3"]
 if args and args[0] == "--wl":
@@ -25,7 +26,7 @@ for name in which:
     sc = rt.Scene.generate(scene)
     for spec in sets:
         opts = {} if spec == "-" else {k: float(v) for k, v in (kv.split("=") for kv in spec.split(","))}
-        r = rt.Renderer(sc, rt.Camera(*cam, *size), max_depth=depth, seed=1, options=opts)
+        r = rt.Renderer(sc, rt.Camera(*cam, *size), max_depth=depth, seed=1, options=opts, sky_mode=1 if name == "cfg4" else 0)
         best = 0
         for _ in range(4):
             r.reset_accumulation(); r.accumulate(spp, spp_begin=0)
