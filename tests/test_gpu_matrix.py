@@ -96,3 +96,25 @@ def test_depth_limits_with_and_without_packets(rt, scene, cam):
             assert got[1][0].any()
         # the image is the sum over samples of sqrt(radiance) (f32 square root: an ulp; fixed point: 2^-36 per sample)
         assert np.allclose(got[1][0], np.sqrt(np.clip(got[1][2], 0.0, 65536.0)).sum(axis=0), rtol=2e-6, atol=1e-6), depth
+
+
+def test_packets_on_adversarial_scenes(rt):
+    """Random adversarial scenes (hollow shells and stand-alone inverted spheres with their gates, coplanar
+    and degenerate cubes, objects around and behind the camera) pushed through the kernels for scenes in
+    global memory: camera rays walked as packets (on full nodes, with quantised nodes beside them or not)
+    render the same words as camera rays walked one by one, and as the LDS kernels."""
+    from util import random_scene
+    w, h = 96, 64
+    for seed in range(16):
+        sc, cam = random_scene(rt, 100 + seed)
+        ref = None
+        for opts in ({}, {"scene_lds": 0}, {"scene_lds": 0, "packet": 0}, {"scene_lds": 0, "qnodes": 0}, {"scene_lds": 0, "threads": 512}):
+            r = rt.Renderer(sc, rt.Camera(*cam, w, h), seed=seed, max_depth=6, options=opts)
+            r.accumulate(6, spp_begin=0)
+            words, rays = r.read_accum(), r.stats()["rays"]
+            r.close()
+            if ref is None:
+                ref, ref_rays = words, rays
+                continue
+            assert rays == ref_rays, (seed, opts)
+            assert np.array_equal(words, ref), (seed, opts)
