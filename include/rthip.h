@@ -116,7 +116,8 @@ int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
  * tiles in LDS: -1 = scenes with nothing below the root, 0 = never, 1 = wherever they fit), "root_leaf" (0 = a scene that is
  * one leaf with no tree is still walked from its root; 1, the default, tests the leaf at ray start and skips the walk), "packet"
  * (scenes in global memory: 1, the default, walks the 64 camera rays of a batch through the tree together as one wave packet
- * whose node reads are scalar loads; 0 = each ray on its own; same image either way), "stack_mem"
+ * whose node reads are scalar loads; 0 = each ray on its own; same image either way), "pixel_major" (what such a packet is made of:
+ * 1 = all samples of a few neighbouring pixels, 0 = one sample of an 8x8 tile, -1, the default = the former from 65 536 primitives on), "stack_mem"
  * (1 = traversal stacks in global memory instead of LDS; measured slower, off), "xchg" (1 = rays waiting to
  * be shaded are regrouped by kind through queues in LDS, with "xchg_cap", "xchg_pop_min", "xchg_push_max";
  * measured slower, off), "threads", "blocks_per_cu", "grid_reserve", "chunk", "trav_threshold", "inner_exit",

@@ -61,6 +61,7 @@ struct Tuning {
 	int xchg_pop_min = 16;    // RTHIP_XCHG_POP_MIN
 	int xchg_push_max = 64;   // RTHIP_XCHG_PUSH_MAX
 	int packet = 1;           // RTHIP_PACKET: the camera rays of a batch walk the tree together, as one packet per wave (f32 megakernel, scenes in global memory; 0 = each on its own)
+	int pixel_major = -1;     // RTHIP_PIXEL_MAJOR: packets of camera rays cover all samples of a few neighbouring pixels (1) or one sample of a tile's 64 pixels (0); -1 = the former from 65 536 primitives on
 	int root_leaf = 1;        // RTHIP_ROOT_LEAF: scenes with one leaf and no tree skip the traversal loop (0 = walk the root like any tree)
 	int acc_lds = -1;         // RTHIP_ACC_LDS: per-wave accumulation tiles in LDS: -1 = scenes with nothing below the root, 0 = never, 1 = wherever they fit
 	int threads = 0;          // RTHIP_THREADS: force the workgroup size (256, 512, 1024), 0 = most resident waves
@@ -82,6 +83,7 @@ struct Tuning {
 		t.acc_lds = env_int("RTHIP_ACC_LDS", t.acc_lds);
 		t.root_leaf = env_int("RTHIP_ROOT_LEAF", t.root_leaf);
 		t.packet = env_int("RTHIP_PACKET", t.packet);
+		t.pixel_major = env_int("RTHIP_PIXEL_MAJOR", t.pixel_major);
 		t.stack_mem = env_int("RTHIP_STACK_MEM", t.stack_mem);
 		t.xchg = env_int("RTHIP_XCHG", t.xchg);
 		t.xchg_cap = env_int("RTHIP_XCHG_CAP", t.xchg_cap);
@@ -527,6 +529,9 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	a.stats = reinterpret_cast<unsigned long long*>(control + 8);
 	a.xchg_off = plan.xchg_off; a.xchg_cap = plan.xchg_cap;
 	a.packet = (c->tune.packet != 0 && c->tree_depth <= 64) ? 1 : 0;   // the wave's stack holds an entry per lane
+	// Narrow packets pay where the walk is long (large scenes); the samples of a pixel then finish at about the
+	// same time and their accumulation adds meet at one address, which costs more than it gains on small scenes.
+	a.pixel_major = c->tune.pixel_major >= 0 ? (c->tune.pixel_major != 0) : (c->n_prims >= 65536);
 	a.xchg_pop_min = std::max(1, std::min(64, c->tune.xchg_pop_min));
 	a.xchg_push_max = std::max(0, std::min(64, c->tune.xchg_push_max));
 	if (plan.cfg.stack_mem) {
@@ -819,6 +824,7 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		else if (k == "acc_lds") t.acc_lds = iv;
 		else if (k == "root_leaf") t.root_leaf = iv;
 		else if (k == "packet") t.packet = iv;
+		else if (k == "pixel_major") t.pixel_major = iv;
 		else if (k == "stack_mem") t.stack_mem = iv;
 		else if (k == "xchg") t.xchg = iv;
 		else if (k == "xchg_cap") t.xchg_cap = iv;

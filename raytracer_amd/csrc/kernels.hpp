@@ -80,6 +80,7 @@ struct RenderArgs {
 	int32_t xchg_pop_min;         // kXchg: take rays out of a queue only this many at a time (or when the wave has nothing else to do)
 	int32_t xchg_push_max;        // kXchg: an arm hands its rays over only when it holds at most this many lanes of the wave
 	int32_t packet;               // camera rays are traced 64 at a time as one packet per wave (kernels that make them in batches)
+	int32_t pixel_major;          // such batches run a work item pixel by pixel (a packet = all samples of a few neighbouring pixels) instead of sample by sample
 };
 
 template <typename Real>
@@ -955,7 +956,8 @@ RT_FN void accumulate_sample(unsigned long long* accum, uint32_t accum_index, V3
 // samples).  Returns false for pixels outside the image and samples beyond spp_count.
 struct PathId { uint32_t px, py, accum_index, s_local; };
 __device__ __forceinline__ bool decode_path(uint32_t item, uint32_t j, uint32_t n_chunks, uint32_t chunk, uint32_t spp_count,
-                                            int32_t part_index, int32_t part_count, int32_t tiles_x, int32_t width, int32_t height, PathId* out, uint32_t block_order = 0u) {
+                                            int32_t part_index, int32_t part_count, int32_t tiles_x, int32_t width, int32_t height, PathId* out, uint32_t block_order = 0u,
+                                            bool sample_major = false) {
 	uint32_t tile_local = item / n_chunks, chunk_i = item - tile_local * n_chunks;
 	uint32_t tile = (uint32_t)part_index + tile_local * (uint32_t)part_count;
 	uint32_t ty = tile / (uint32_t)tiles_x, tx = tile - ty * (uint32_t)tiles_x;
@@ -974,10 +976,23 @@ __device__ __forceinline__ bool decode_path(uint32_t item, uint32_t j, uint32_t 
 		tx = sx * S + lx; ty = band * S + ly;
 		tile = ty * (uint32_t)tiles_x + tx;
 	}
-	out->px = tx * kTile + (j & 7u);
-	out->py = ty * kTile + ((j >> 3) & 7u);
-	out->s_local = chunk_i * chunk + (j >> 6);
-	out->accum_index = tile * kTilePixels + (j & 63u);
+	// Which path of the item path j is.  By default the item is run sample by sample: 64 consecutive paths are
+	// one sample of the tile's 64 pixels.  sample_major runs it pixel by pixel, the pixels in Morton order:
+	// 64 consecutive paths are then all samples of a few neighbouring pixels, i.e. rays that differ by a
+	// pixel or two, which is what a packet of camera rays wants (the union of its rays' walks stays short).
+	uint32_t x = j & 7u, y = (j >> 3) & 7u, s_in = j >> 6;
+	if (sample_major) {
+		uint32_t q = (uint32_t)((float)j * __builtin_amdgcn_rcpf((float)chunk));  // j / chunk (j < 64 * chunk): the hardware reciprocal is an ulp off at most,
+		if (q * chunk > j) q--;                                                   // so one step either way settles it
+		else if ((q + 1u) * chunk <= j) q++;
+		s_in = j - q * chunk;
+		x = (q & 1u) | ((q >> 1) & 2u) | ((q >> 2) & 4u);
+		y = ((q >> 1) & 1u) | ((q >> 2) & 2u) | ((q >> 3) & 4u);
+	}
+	out->px = tx * kTile + x;
+	out->py = ty * kTile + y;
+	out->s_local = chunk_i * chunk + s_in;
+	out->accum_index = tile * kTilePixels + (y * 8u + x);
 	return out->px < (uint32_t)width && out->py < (uint32_t)height && out->s_local < spp_count;
 }
 
@@ -1365,7 +1380,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 					PathId id;
 					Rng g;
 					g.state = 0; g.inc = 1;
-					if (lane < n && decode_path(item, pool_pos + lane, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order)) {
+					if (lane < n && decode_path(item, pool_pos + lane, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order, first_hit && A.pixel_major != 0)) {
 						g.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
 						const RayT<Real> r = camera_ray<Real>(A.cam, (Real)id.px, (Real)id.py, g, true);
 						sp_o = r.o; sp_d = r.d;
@@ -1397,13 +1412,15 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 								                                       A.big_leaf, A.start, tally, rg);
 							}
 							bool live = false;
+							unsigned long long done_r = 0ull, done_g = 0ull, done_b = 0ull;   // the sample of a path that ends here
+							uint32_t done_pixel = 0xFFFFFFFFu;                                 // this lane's place in the accumulation buffer
 							{
 								const uint32_t n_valid = (uint32_t)__popcll(__ballot(sp_valid));
 								w_paths += n_valid; w_rays += n_valid;
 							}
 							if (sp_valid) {
 								// (pixel and random stream are worked out again here rather than kept in registers through the walk)
-								decode_path(sp_item, sp_base + lane, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order);
+								decode_path(sp_item, sp_base + lane, A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order, A.pixel_major != 0);
 								g.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);
 								const int draws = A.cam.defocus_angle > Real(0) ? 4 : 2;  // camera_ray: two for the jitter, two for the lens
 								for (int k = 0; k < draws; k++) g.skip();
@@ -1418,13 +1435,28 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 										Real* so = A.samples_out + ((size_t)(id.s_local * (uint32_t)A.height + id.py) * (uint32_t)A.width + id.px) * 3;
 										so[0] = L1.x; so[1] = L1.y; so[2] = L1.z;
 									}
+									done_r = to_fixed<Real>(Fp<Real>::sqrt(L1.x)); done_g = to_fixed<Real>(Fp<Real>::sqrt(L1.y)); done_b = to_fixed<Real>(Fp<Real>::sqrt(L1.z));
+								}
+								done_pixel = id.accum_index;
+							}
+							// Where the batch runs pixel by pixel, the lanes of one pixel stand side by side: their samples are
+							// summed along the wave first (integer sums: any order gives the same words) and the first lane
+							// of each pixel adds the total, instead of up to 64 lanes hitting one address.
+							for (int off = 1; off < 64 && A.pixel_major != 0; off <<= 1) {   // (sample by sample, every lane has a pixel of its own)
+								const uint32_t other = (uint32_t)__shfl_down((int)done_pixel, off, 64);
+								const unsigned long long r2 = __shfl_down(done_r, off, 64), g2 = __shfl_down(done_g, off, 64), b2 = __shfl_down(done_b, off, 64);
+								if (lane + (uint32_t)off < 64u && other == done_pixel) { done_r += r2; done_g += g2; done_b += b2; }
+							}
+							{
+								const uint32_t before = (uint32_t)__shfl_up((int)done_pixel, 1, 64);
+								const bool head = A.pixel_major == 0 || lane == 0u || before != done_pixel;
+								if (head && done_pixel != 0xFFFFFFFFu && (done_r | done_g | done_b) != 0ull) {
 									if constexpr (kAccLds) {
-										unsigned long long* acc = acc_tile + (id.accum_index & 63u);
-										atomicAdd(acc, to_fixed<Real>(Fp<Real>::sqrt(L1.x)));
-										atomicAdd(acc + kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L1.y)));
-										atomicAdd(acc + 2 * kTilePixels, to_fixed<Real>(Fp<Real>::sqrt(L1.z)));
+										unsigned long long* acc = acc_tile + (done_pixel & 63u);
+										atomicAdd(acc, done_r); atomicAdd(acc + kTilePixels, done_g); atomicAdd(acc + 2 * kTilePixels, done_b);
 									} else {
-										accumulate_sample<Real>(A.accum, id.accum_index, L1);
+										unsigned long long* acc = A.accum + (size_t)(done_pixel >> 6) * (kTilePixels * kAccumChannels) + (done_pixel & 63u);
+										atomicAdd(acc, done_r); atomicAdd(acc + kTilePixels, done_g); atomicAdd(acc + 2 * kTilePixels, done_b);
 									}
 								}
 							}
@@ -1459,7 +1491,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 						const uint32_t st = (uint32_t)__shfl((int)sp_fh_state, src, 64), hit = (uint32_t)__shfl((int)sp_fh_hit, src, 64);
 						if (mine) {
 							PathId id;
-							decode_path(sp_item, sp_base + (hit & 63u), A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order);
+							decode_path(sp_item, sp_base + (hit & 63u), A.n_chunks, A.chunk, A.spp_count, A.part_index, A.part_count, A.tiles_x, A.width, A.height, &id, kLds != 0 ? 0u : A.block_order, A.pixel_major != 0);
 							rng.init(A.seed, id.py * (uint32_t)A.width + id.px, A.spp_begin + id.s_local);   // for the stream's increment
 							rng.state = st;
 							accum_index = id.accum_index;

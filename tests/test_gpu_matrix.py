@@ -41,7 +41,8 @@ def test_launch_options_change_no_word(rt, scene, cam, sky):
     """The launch-side experiments and shortcuts (rays regrouped by shading arm through LDS queues, with
     small and with large queues; traversal stacks in global memory; both at once; a one-leaf scene walked
     from its root instead of tested at ray start; other workgroup sizes; for scenes in global memory the
-    camera rays walked one by one instead of 64 at a time as a packet, on full and on quantised nodes) render the same accumulation
+    camera rays walked one by one instead of 64 at a time as a packet, on full and on quantised nodes, the packets made of one sample
+    of 64 pixels or of all samples of a few pixels) render the same accumulation
     words as the defaults: paths are deterministic and accumulation is integer, so which lane, wave or
     workgroup carries a ray, and where its stack lives, cannot show in the image."""
     sc = rt.Scene.generate(scene)
@@ -49,7 +50,8 @@ def test_launch_options_change_no_word(rt, scene, cam, sky):
     ref = None
     for opts in ({}, {"xchg": 1}, {"xchg": 1, "xchg_cap": 64, "xchg_pop_min": 8}, {"xchg": 1, "xchg_push_max": 6, "xchg_pop_min": 40},
                  {"stack_mem": 1}, {"xchg": 1, "stack_mem": 1}, {"root_leaf": 0}, {"threads": 256}, {"threads": 512}, {"chunk": 3}, {"packet": 0}, {"packet": 0, "qnodes": 0}, {"qnodes": 0},
-                 {"scene_lds": 0}, {"scene_lds": 0, "packet": 0}):
+                 {"scene_lds": 0}, {"scene_lds": 0, "packet": 0}, {"scene_lds": 0, "pixel_major": 1}, {"scene_lds": 0, "pixel_major": 1, "chunk": 5},
+                 {"pixel_major": 0}, {"pixel_major": 1, "chunk": 16}):
         r = rt.Renderer(sc, rt.Camera(*cam[:5], w, h), seed=3, max_depth=12, sky_mode=sky, options=opts)
         r.accumulate(16, spp_begin=0)       # 3.7 M paths: long enough for the queues to be used (short launches leave them out) and served
         _, n = r.accum_buffer()
@@ -108,7 +110,8 @@ def test_packets_on_adversarial_scenes(rt):
     for seed in range(16):
         sc, cam = random_scene(rt, 100 + seed)
         ref = None
-        for opts in ({}, {"scene_lds": 0}, {"scene_lds": 0, "packet": 0}, {"scene_lds": 0, "qnodes": 0}, {"scene_lds": 0, "threads": 512}):
+        for opts in ({}, {"scene_lds": 0}, {"scene_lds": 0, "packet": 0}, {"scene_lds": 0, "qnodes": 0}, {"scene_lds": 0, "threads": 512},
+                     {"scene_lds": 0, "pixel_major": 1}, {"scene_lds": 0, "pixel_major": 1, "chunk": 3}):
             r = rt.Renderer(sc, rt.Camera(*cam, w, h), seed=seed, max_depth=6, options=opts)
             r.accumulate(6, spp_begin=0)
             words, rays = r.read_accum(), r.stats()["rays"]
