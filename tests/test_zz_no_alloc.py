@@ -139,3 +139,23 @@ def test_noalloc_after_a_reduce_and_under_graph_capture(rt):
     assert np.array_equal(buf.cpu().numpy().view(np.uint64), six)
     del graph
     g.close()
+
+
+def test_noalloc_on_a_scene_in_global_memory(rt):
+    """The same comparison on a scene whose tree stays in global memory (quantised nodes, camera rays walked
+    as packets): those kernels take nothing from the allocator either, and two calls in a row, the second
+    smaller, render the words of the allocating entry point."""
+    sc = rt.Scene.generate("synthetic:5000")
+    cam5 = ((0.0, 60.0, -550.0), (0.0, -60.0, 550.0), 40.0, 10.0, 0.0)
+    r = rt.Renderer(sc, rt.Camera(*cam5, 480, 270), seed=43, max_depth=8)
+    for (w, h, spp) in ((480, 270, 5), (160, 96, 2)):
+        r.update_camera(rt.Camera(*cam5, w, h))
+        r.accumulate(spp, spp_begin=0)
+        want, want_stats = _words(r), r.stats()
+        assert not want_stats["scene_in_lds"]
+        r.reset_accumulation()
+        r.accumulate(spp, spp_begin=0, noalloc=True)
+        got, got_stats = _words(r), r.stats()
+        assert np.array_equal(got, want), (w, h, spp)
+        assert got_stats["paths"] == want_stats["paths"] == w * h * spp and got_stats["rays"] == want_stats["rays"]
+    r.close()
