@@ -349,13 +349,14 @@ int32_t validate(rthip_ctx* c, const rthip_render_params* p) {
 }
 
 // Resident workgroups per CU, asked of the runtime once per kernel variant and LDS size.
-int32_t blocks_per_cu(rthip_ctx* c, bool f64, bool wavefront, int threads, int lds_mode, bool quantised, size_t lds, int* out, bool acc_lds = false, bool stack_mem = false, bool xchg = false) {
-	const auto key = std::make_tuple(f64, wavefront, threads, lds_mode + (acc_lds ? 8 : 0) + (stack_mem ? 16 : 0) + (xchg ? 32 : 0), quantised, lds);
+int32_t blocks_per_cu(rthip_ctx* c, bool f64, bool wavefront, int threads, int lds_mode, bool quantised, size_t lds, int* out, bool acc_lds = false, bool stack_mem = false, bool xchg = false,
+                      bool root_only = false) {
+	const auto key = std::make_tuple(f64, wavefront, threads, lds_mode + (acc_lds ? 8 : 0) + (stack_mem ? 16 : 0) + (xchg ? 32 : 0) + (root_only ? 64 : 0), quantised, lds);
 	auto it = c->occupancy.find(key);
 	if (it != c->occupancy.end()) { *out = it->second; return RTHIP_OK; }
 	int b = 0;
 	if (wavefront) HIP_TRY(c, f64 ? wf_extend_blocks_per_cu_f64(threads, lds_mode != 0, lds, &b) : wf_extend_blocks_per_cu_f32(threads, lds_mode != 0, lds, &b));
-	else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, lds_mode, lds, &b) : render_blocks_per_cu_f32(threads, lds_mode, lds, &b, quantised, acc_lds, stack_mem, xchg));
+	else HIP_TRY(c, f64 ? render_blocks_per_cu_f64(threads, lds_mode, lds, &b) : render_blocks_per_cu_f32(threads, lds_mode, lds, &b, quantised, acc_lds, stack_mem, xchg, root_only));
 	c->occupancy[key] = b;
 	*out = b;
 	return RTHIP_OK;
@@ -421,7 +422,9 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// the launches before it; only where the tiles cost no resident wave, and not for launches of a
 	// few samples, whose items are one wave's worth of paths anyway.
 	plan->cfg.acc_lds = false;
+	plan->cfg.root_only = false;
 	plan->cfg.acc_tile_off = 0;
+	const bool one_leaf = c->root_leaf != 0 && tune.root_leaf != 0;   // the launch tests that leaf at ray start and walks nothing: there is a kernel without the walk
 	const bool acc_wanted = tune.acc_lds > 0 || (tune.acc_lds < 0 && c->n_nodes <= 1);
 	if (acc_wanted && !f64 && !wavefront && !count && !stack_mem && !xchg && plan->cfg.lds_mode == 2 && p->spp_count >= 8) {
 		for (int threads : {256, 512}) {
@@ -429,11 +432,12 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 			const size_t base = (size_t)c->tree_depth * threads * 4 + blob.lds_bytes_mats;
 			const size_t lds = base + (size_t)(threads / 64) * kTilePixels * kAccumChannels * 8;
 			int b = 0;
-			int32_t rc = blocks_per_cu(c, f64, wavefront, threads, 2, false, lds, &b, true);
+			int32_t rc = blocks_per_cu(c, f64, wavefront, threads, 2, false, lds, &b, true, false, false, one_leaf);
 			if (rc != RTHIP_OK) return rc;
 			if (b * threads / 64 >= best_waves && (!plan->cfg.acc_lds || b * threads / 64 > best_waves)) {
 				best_waves = b * threads / 64; bpc = b;
 				plan->cfg.threads = threads; plan->cfg.dyn_lds = lds; plan->cfg.acc_lds = true; plan->cfg.acc_tile_off = (uint32_t)base;
+				plan->cfg.root_only = one_leaf;
 			}
 		}
 	}

@@ -44,6 +44,9 @@ namespace rthip {
 #ifndef RT_MINWAVES
 #define RT_MINWAVES 6
 #endif
+#ifndef RT_ROOTWAVES
+#define RT_ROOTWAVES 7   // the kernel of one-leaf scenes (no traversal code): 68 registers
+#endif
 constexpr uint32_t kQueues = 8;   // work-item ranges, one per XCD of the part
 constexpr int kProbeBlock = 256;  // threads per workgroup of the parity probe
 constexpr int kDone = INT32_MIN;  // traversal finished (not a valid leaf code)
@@ -1055,8 +1058,11 @@ __device__ __forceinline__ void xchg_order() { asm volatile("" ::: "memory"); }
 // with and without its camera's defocus arithmetic), and only where LDS has the room.
 // kStackMem: the lanes' traversal stacks in global memory (StackMem) instead of LDS.
 // kXchg: rays waiting to be shaded are regrouped by shading arm through queues in LDS (see Xchg).
-template <typename Real, int kThreads, int kLds, bool kCount, bool kQ = false, bool kAccLds = false, bool kStackMem = false, bool kXchg = false>
-__global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? (kThreads == 1024 ? 8 : (kQ ? RT_QWAVES : RT_MINWAVES)) : 2)) void render_kernel(RenderArgs<Real> A) {
+// kRootOnly: the scene is one leaf (RenderArgs::start == kDone): every ray tests that leaf when it is set up and goes
+// on to shading; without the traversal code the kernel needs 70 registers and seven waves per SIMD fit.
+template <typename Real, int kThreads, int kLds, bool kCount, bool kQ = false, bool kAccLds = false, bool kStackMem = false, bool kXchg = false, bool kRootOnly = false>
+__global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_MINWAVES ? (kThreads == 1024 ? 8 : (kRootOnly ? RT_ROOTWAVES : (kQ ? RT_QWAVES : RT_MINWAVES))) : 2)) void render_kernel(RenderArgs<Real> A) {
+	static_assert(!kRootOnly || (kAccLds && !kQ && !kStackMem && !kXchg), "the one-leaf kernel exists with accumulation tiles only");
 	static_assert(!kQ || (kLds == 0 && std::is_same<Real, float>::value), "quantised nodes: f32 trees in global memory only");
 	static_assert(!kXchg || (kLds != 0 && !kAccLds && std::is_same<Real, float>::value), "exchange queues: f32, scene in LDS, no accumulation tiles");
 	extern __shared__ __align__(64) char smem[];
@@ -1597,12 +1603,14 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				leaf_tests<Real, kCount>(tv, leaf_ray<kQ, Real>(ray), A.big_leaf, prims, gates, tally, rg);
 				tv.cur = A.start;
 			}
-			state = A.start == kDone ? kShade : kTraverse;  // (a scene that is one leaf: nothing to walk)
+			if constexpr (kRootOnly) state = kShade;
+			else state = A.start == kDone ? kShade : kTraverse;  // (a scene that is one leaf: nothing to walk)
 		}
 		phase_end<kCount>(rg, kPhFresh, t_ph);
 
 		// ---- traversal: until few lanes are left traversing while others wait -------------
 		for (;;) {
+			if constexpr (kRootOnly) break;   // (no tree: the loop, the stacks and the box-test operands of a ray are not in this kernel)
 			unsigned long long m = __ballot(state == kTraverse);
 			if (m == 0ull) break;
 			uint32_t n_trav = (uint32_t)__popcll(m);

@@ -44,7 +44,9 @@ hipError_t launch_finalize(const unsigned long long* accum, void* out, int width
 }
 
 hipError_t wf_extend_blocks_per_cu_f32(int threads, bool scene_in_lds, size_t dyn_lds, int* blocks) { return wf_extend_blocks_per_cu_impl(threads, scene_in_lds, dyn_lds, blocks); }
-hipError_t render_blocks_per_cu_f32(int threads, int lds_mode, size_t dyn_lds, int* blocks, bool quantised, bool acc_lds, bool stack_mem, bool xchg) { return blocks_per_cu_impl(threads, lds_mode, dyn_lds, blocks, quantised, acc_lds, stack_mem, xchg); }
+hipError_t render_blocks_per_cu_f32(int threads, int lds_mode, size_t dyn_lds, int* blocks, bool quantised, bool acc_lds, bool stack_mem, bool xchg, bool root_only) {
+	return blocks_per_cu_impl(threads, lds_mode, dyn_lds, blocks, quantised, acc_lds, stack_mem, xchg, root_only);
+}
 
 // Streams both buffers once: 24 bytes of HBM traffic per word, two words per thread and trip.
 __global__ __launch_bounds__(256) void add_words_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, uint64_t n) {

@@ -19,6 +19,7 @@ struct LaunchCfg {
 	bool quantised;      // f32, scene in global memory: traverse the 32-byte quantised nodes
 	uint32_t acc_tile_off;  // acc_lds: where the tiles start in the workgroup's dynamic LDS
 	bool acc_lds;        // f32, lds_mode 2: samples go to a per-wave tile in LDS, flushed once per work item
+	bool root_only;      // with acc_lds: the scene is one leaf, the kernel without traversal code
 	bool stack_mem;      // f32, scene in LDS: the lanes' traversal stacks in global memory instead of LDS
 	bool xchg;           // f32, scene in LDS: rays waiting to be shaded are regrouped by shading arm through queues in LDS
 };
@@ -28,7 +29,8 @@ hipError_t launch_render(const RenderArgs<double>& a, const LaunchCfg& cfg, hipS
 hipError_t launch_probe(const ProbeArgs<float>& a, size_t dyn_lds, hipStream_t s);
 hipError_t launch_probe(const ProbeArgs<double>& a, size_t dyn_lds, hipStream_t s);
 // Resident workgroups per CU for the render kernel at this much dynamic LDS.
-hipError_t render_blocks_per_cu_f32(int threads, int lds_mode, size_t dyn_lds, int* blocks, bool quantised = false, bool acc_lds = false, bool stack_mem = false, bool xchg = false);
+hipError_t render_blocks_per_cu_f32(int threads, int lds_mode, size_t dyn_lds, int* blocks, bool quantised = false, bool acc_lds = false, bool stack_mem = false, bool xchg = false,
+                                    bool root_only = false);
 hipError_t render_blocks_per_cu_f64(int threads, int lds_mode, size_t dyn_lds, int* blocks);
 // Accumulation buffer (tile-major fixed point) -> row-major [H][W][3] doubles (sums).
 hipError_t launch_unpack(const unsigned long long* accum, double* rgb, int width, int height, int tiles_x, hipStream_t s);
