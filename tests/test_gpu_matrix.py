@@ -121,3 +121,27 @@ def test_packets_on_adversarial_scenes(rt):
                 continue
             assert rays == ref_rays, (seed, opts)
             assert np.array_equal(words, ref), (seed, opts)
+
+
+def test_shares_add_up_on_a_large_scene(rt):
+    """A scene of more than 65 536 primitives (global memory, quantised nodes, packets made of all samples of
+    a few pixels, work items taken in blocks of tiles): tile shares and sample shares rendered one after the
+    other into one buffer give the words of the whole render, whatever the chunk."""
+    sc = rt.Scene.generate("synthetic:70000")
+    w, h, spp = 200, 136, 9           # a frame whose last tile column and row are partial
+    for opts in ({}, {"chunk": 4}, {"pixel_major": 0}):
+        r = rt.Renderer(sc, rt.Camera(*CAM5[:5], w, h), seed=9, max_depth=10, options=opts)
+        r.accumulate(spp, spp_begin=0)
+        whole, rays = r.read_accum(), r.stats()["rays"]
+        r.reset_accumulation()
+        total = 0
+        for part in range(3):
+            r.accumulate(spp, part=(part, 3), spp_begin=0)
+            total += r.stats()["rays"]
+        assert np.array_equal(r.read_accum(), whole), opts
+        assert total == rays
+        r.reset_accumulation()
+        for begin, count in ((0, 2), (2, 6), (8, 1)):
+            r.accumulate(count, spp_begin=begin)
+        assert np.array_equal(r.read_accum(), whole), opts
+        r.close()
