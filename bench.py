@@ -332,18 +332,24 @@ def main():
                                    node_visits_per_path=s["box_tests"] / 2 / max(1, s["paths"]),
                                    prim_tests_per_path=(s["sphere_tests"] + s["cube_tests"]) / max(1, s["paths"]))
             r.set_option("count", 0)
-        # the 1-spp progressive frame (raytracer_runtime-style caller): ms per frame
+        # the 1-spp progressive frame (raytracer_runtime-style caller): ms per frame of a queue of frames on the
+        # context's own stream, where the library lets the tail of one short launch run under the start of the
+        # next (option overlap), and with one launch after the other
         if rank == 0 and name == "cfg2" and not args.no_extra and not multi and precision == rt.F32:
             r.set_accum_buffer(0, 0)
-            r.reset_accumulation()
-            for _ in range(3):
-                r.accumulate(1)
-            torch.cuda.synchronize(device)
-            t1 = time.perf_counter()
-            for _ in range(20):
-                r.accumulate(1, sync=False)
-            r.synchronize()
-            out["frame_ms_1spp"] = (time.perf_counter() - t1) / 20 * 1e3
+            r.set_stream(0)
+            for key, overlap in (("frame_ms_1spp", 1), ("frame_ms_1spp_serial", 0)):
+                r.set_option("overlap", overlap)
+                r.reset_accumulation()
+                for _ in range(6):
+                    r.accumulate(1, sync=False)
+                r.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(60):
+                    r.accumulate(1, sync=False)
+                r.synchronize()
+                out[key] = (time.perf_counter() - t1) / 60 * 1e3
+            r.set_option("overlap", 1)
         r.close()
         return out
 
@@ -417,6 +423,7 @@ def main():
                 line["predicted_scaling"] = pred
         if "frame_ms_1spp" in res:
             line["frame_ms_1080p_1spp"] = res["frame_ms_1spp"]
+            line["frame_ms_1080p_1spp_one_after_the_other"] = res["frame_ms_1spp_serial"]
 
         def rooflines(name, rs, work):
             """The roofline objects of one workload from its run `rs` and the oracle's count `work`."""

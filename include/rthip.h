@@ -116,7 +116,10 @@ int32_t rthip_set_stream(rthip_ctx* ctx, void* hip_stream);
  * tiles in LDS: -1 = scenes with nothing below the root, 0 = never, 1 = wherever they fit), "root_leaf" (0 = a scene that is
  * one leaf with no tree is still walked from its root; 1, the default, tests the leaf at ray start and skips the walk), "packet"
  * (scenes in global memory: 1, the default, walks the 64 camera rays of a batch through the tree together as one wave packet
- * whose node reads are scalar loads; 0 = each ray on its own; same image either way), "pixel_major" (what such a packet is made of:
+ * whose node reads are scalar loads; 0 = each ray on its own; same image either way), "overlap" (1, the default: short launches queued with
+ * rthip_render_accumulate_async on the context's OWN stream take turns on three streams, so that the tail of one runs under the start of
+ * the next; samples are integer adds, so the sum is the same, and every other call on the context is ordered behind all of them;
+ * 0 = one launch after the other; with a caller-owned stream launches always follow one another on that stream), "pixel_major" (what such a packet is made of:
  * 1 = all samples of a few neighbouring pixels, 0 = one sample of an 8x8 tile, -1, the default = the former from 65 536 primitives on), "stack_mem"
  * (1 = traversal stacks in global memory instead of LDS; measured slower, off), "xchg" (1 = rays waiting to
  * be shaded are regrouped by kind through queues in LDS, with "xchg_cap", "xchg_pop_min", "xchg_push_max";

@@ -60,6 +60,7 @@ struct Tuning {
 	int xchg_cap = 128;       // RTHIP_XCHG_CAP: records per queue (rounded down to a power of two, 64 at least)
 	int xchg_pop_min = 16;    // RTHIP_XCHG_POP_MIN
 	int xchg_push_max = 64;   // RTHIP_XCHG_PUSH_MAX
+	int overlap = 1;          // RTHIP_OVERLAP: short launches on the context's own stream take turns on three streams, so that the tail of one runs under the start of the next
 	int packet = 1;           // RTHIP_PACKET: the camera rays of a batch walk the tree together, as one packet per wave (f32 megakernel, scenes in global memory; 0 = each on its own)
 	int pixel_major = -1;     // RTHIP_PIXEL_MAJOR: packets of camera rays cover all samples of a few neighbouring pixels (1) or one sample of a tile's 64 pixels (0); -1 = the former from 65 536 primitives on
 	int root_leaf = 1;        // RTHIP_ROOT_LEAF: scenes with one leaf and no tree skip the traversal loop (0 = walk the root like any tree)
@@ -83,6 +84,7 @@ struct Tuning {
 		t.acc_lds = env_int("RTHIP_ACC_LDS", t.acc_lds);
 		t.root_leaf = env_int("RTHIP_ROOT_LEAF", t.root_leaf);
 		t.packet = env_int("RTHIP_PACKET", t.packet);
+		t.overlap = env_int("RTHIP_OVERLAP", t.overlap);
 		t.pixel_major = env_int("RTHIP_PIXEL_MAJOR", t.pixel_major);
 		t.stack_mem = env_int("RTHIP_STACK_MEM", t.stack_mem);
 		t.xchg = env_int("RTHIP_XCHG", t.xchg);
@@ -110,6 +112,22 @@ struct rthip_ctx {
 	int num_cu = 0;
 	hipStream_t own_stream = nullptr, stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	// Short launches (a viewer's 1-spp frames) end in a tail of a few long paths in nearly empty waves.  Samples
+	// are integer adds into the accumulation buffer, so consecutive launches need no order among themselves:
+	// on the context's own stream they take turns on that stream and two side streams, each with a control
+	// block and events of its own, and the tail of one runs under the start of the next.  Every other call
+	// first orders the own stream behind the side streams (join_lanes).
+	struct Lane {
+		hipStream_t stream = nullptr;
+		char* control = nullptr;
+		hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
+		bool busy = false;
+	};
+	static constexpr int kSideLanes = 2;
+	Lane side[kSideLanes];
+	hipEvent_t fork = nullptr;          // recorded on the own stream before a launch goes to a side stream
+	int lane_turn = 0;                  // whose turn the next short launch is: 0 = the own stream, k = side[k - 1]
+	hipEvent_t last_ev0 = nullptr, last_ev1 = nullptr;   // the timing events of the last launch
 	hipEvent_t noalloc_done = nullptr;  // recorded behind every launch of rthip_render_accumulate_noalloc
 	std::string err;
 
@@ -168,9 +186,14 @@ int32_t fail(rthip_ctx* c, int32_t code, const std::string& msg) noexcept {
 }
 // Every extern "C" body runs inside this: nothing a C++ library routine throws (bad_alloc from a
 // vector, a thread that cannot start) may unwind across the C ABI.
+int32_t join_lanes(rthip_ctx* c);
 template <typename F>
-int32_t guarded(rthip_ctx* c, F&& body) noexcept {
+int32_t guarded(rthip_ctx* c, F&& body, bool join = true) noexcept {
 	try {
+		if (c && join) {  // what the context spread over its side streams comes first (see rthip_ctx::Lane)
+			const int32_t rc = join_lanes(c);
+			if (rc != RTHIP_OK) return rc;
+		}
 		return body();
 	} catch (const std::bad_alloc&) {
 		return fail(c, RTHIP_ERR_LIMIT, "out of host memory");
@@ -331,6 +354,7 @@ struct Plan {
 	uint32_t chunk, n_chunks, n_items;
 	int32_t threshold;
 	int waves_per_cu;             // resident waves per CU the launch is planned for
+	bool short_launch;            // fewer paths than 512 per resident wave (a viewer's 1-spp frame)
 	uint32_t xchg_off, xchg_cap;  // exchange queues: where they start in the workgroup's LDS, records per queue
 };
 
@@ -380,7 +404,9 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// Short launches (a viewer's 1-spp frame at 1080p: ~340 paths per resident wave) are all start-up
 	// and tail: small workgroups start sooner and finish closer together, which is worth more there than
 	// resident waves (0.38 ms against 0.46 ms for that frame).
+	plan->short_launch = false;
 	const bool short_launch = in_lds && !wavefront && my_tiles * kTilePixels * (uint64_t)p->spp_count < 512ull * 24 * (uint64_t)c->num_cu;
+	plan->short_launch = short_launch;
 	// Stacks in global memory: f32 megakernel with the scene in LDS (what the freed LDS is for is decided below).
 	const bool stack_mem = tune.stack_mem > 0 && (in_lds || plan->cfg.quantised) && !f64 && !wavefront && !frugal;  // (the entry point that allocates nothing keeps its stacks in LDS)
 	plan->cfg.stack_mem = stack_mem;
@@ -498,12 +524,35 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	return RTHIP_OK;
 }
 
+// Orders the context's own stream behind whatever its side streams still run (a stream wait, no host wait).
+int32_t join_lanes(rthip_ctx* c) {
+	for (auto& l : c->side) {
+		if (!l.busy) continue;
+		HIP_TRY(c, hipSetDevice(c->device));
+		HIP_TRY(c, hipStreamWaitEvent(c->own_stream, l.done, 0));
+		l.busy = false;
+	}
+	c->lane_turn = 0;
+	return RTHIP_OK;
+}
+// A side lane's stream, control block and events, made when first used.
+int32_t ensure_lane(rthip_ctx* c, rthip_ctx::Lane* l) {
+	if (!c->fork) HIP_TRY(c, hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+	if (!l->stream) HIP_TRY(c, hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+	if (!l->ev0) HIP_TRY(c, hipEventCreate(&l->ev0));
+	if (!l->ev1) HIP_TRY(c, hipEventCreate(&l->ev1));
+	if (!l->done) HIP_TRY(c, hipEventCreateWithFlags(&l->done, hipEventDisableTiming));
+	if (!l->control) HIP_TRY(c, hipMalloc(&l->control, kControlBytes));
+	return RTHIP_OK;
+}
+
 // `frugal` (rthip_render_accumulate_noalloc): nothing may be allocated, and the stream may be under
 // graph capture, where events cannot be queried afterwards: `timed` = false then leaves out the
 // timing events and the statistics of the launch.
 template <typename Real>
 int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, unsigned long long* accum, Real* samples_out, char* control = nullptr,
-                       bool frugal = false, bool timed = true) {
+                       bool frugal = false, bool timed = true, bool may_overlap = false) {
+	may_overlap = may_overlap && !control && !frugal && timed && !samples_out && c->stream == c->own_stream;
 	if (!control) control = c->d_control;
 	if (samples_out && std::is_same<Real, float>::value) count = true;   // only the instrumented f32 kernels write per-sample radiance
 	Plan plan;
@@ -549,11 +598,32 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 		}
 		a.stack_mem = c->stack_mem;
 	}
-	HIP_TRY(c, hipMemsetAsync(control, 0, kControlBytes, c->stream));
-	if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-	if (plan.n_items > 0 && p->spp_count > 0) HIP_TRY(c, launch_render(a, plan.cfg, c->stream));
+	// Which stream the launch goes to: the context's, or (short launches on its own stream) the next in turn.
+	hipStream_t stream = c->stream;
+	hipEvent_t ev0 = c->ev0, ev1 = c->ev1;
+	rthip_ctx::Lane* lane = nullptr;
+	if (may_overlap && plan.short_launch && !plan.cfg.stack_mem) {
+		if (c->lane_turn > 0) {
+			lane = &c->side[c->lane_turn - 1];
+			if ((rc = ensure_lane(c, lane)) != RTHIP_OK) return rc;
+			// behind what the context has queued so far (buffer clears, uploads), not behind its launches in flight
+			HIP_TRY(c, hipEventRecord(c->fork, c->own_stream));
+			HIP_TRY(c, hipStreamWaitEvent(lane->stream, c->fork, 0));
+			stream = lane->stream; ev0 = lane->ev0; ev1 = lane->ev1; control = lane->control;
+			a.queue = reinterpret_cast<uint32_t*>(control + 512);
+			a.stats = reinterpret_cast<unsigned long long*>(control + 8);
+		}
+		c->lane_turn = (c->lane_turn + 1) % (rthip_ctx::kSideLanes + 1);
+	} else if ((rc = join_lanes(c)) != RTHIP_OK) {   // a launch of full size, or one that is not the context's to spread: one after the other
+		return rc;
+	}
+	HIP_TRY(c, hipMemsetAsync(control, 0, kControlBytes, stream));
+	if (timed) HIP_TRY(c, hipEventRecord(ev0, stream));
+	if (plan.n_items > 0 && p->spp_count > 0) HIP_TRY(c, launch_render(a, plan.cfg, stream));
 	if (!timed) return RTHIP_OK;  // a captured launch: its statistics stay in the control block, nobody reads them
-	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+	HIP_TRY(c, hipEventRecord(ev1, stream));
+	if (lane) { HIP_TRY(c, hipEventRecord(lane->done, stream)); lane->busy = true; }
+	c->last_ev0 = ev0; c->last_ev1 = ev1;
 	c->launch_pending = true;
 	c->last_control = control;
 	c->last_in_lds = plan.cfg.scene_in_lds;
@@ -634,6 +704,7 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 		}
 	}
 	HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+	c->last_ev0 = c->ev0; c->last_ev1 = c->ev1;
 	c->launch_pending = true;
 	c->last_control = c->d_control;
 	c->last_in_lds = plan.cfg.scene_in_lds;
@@ -643,7 +714,10 @@ int32_t enqueue_wavefront(rthip_ctx* c, const rthip_render_params* p, unsigned l
 
 int32_t collect_stats(rthip_ctx* c) {
 	if (!c->launch_pending) return RTHIP_OK;
+	int32_t rc_join = join_lanes(c);
+	if (rc_join != RTHIP_OK) return rc_join;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if (c->stream != c->own_stream) HIP_TRY(c, hipStreamSynchronize(c->own_stream));   // (side streams were joined into the own stream)
 	unsigned long long s[5 + 2 * kRegCount + kPhCount];
 	HIP_TRY(c, hipMemcpy(s, (c->last_control ? c->last_control : c->d_control) + 8, sizeof(s), hipMemcpyDeviceToHost));
 	if (!c->tune.region_dump.empty() && c->tune.count) {  // instrumented runs: lane utilisation per code region
@@ -661,7 +735,7 @@ int32_t collect_stats(rthip_ctx* c) {
 		}
 	}
 	float ms = 0.f;
-	HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	HIP_TRY(c, hipEventElapsedTime(&ms, c->last_ev0 ? c->last_ev0 : c->ev0, c->last_ev1 ? c->last_ev1 : c->ev1));
 	c->stats.paths = s[0]; c->stats.rays = s[1]; c->stats.box_tests = s[2]; c->stats.sphere_tests = s[3]; c->stats.cube_tests = s[4];
 	c->stats.kernel_ms = ms;
 	c->stats.scene_in_lds = c->last_in_lds ? 1 : 0;
@@ -768,6 +842,14 @@ void rthip_destroy(rthip_ctx* c) {
 		if (c->stream) (void)hipStreamSynchronize(c->stream);
 		forget_scratch_use(c);
 		if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
+		for (auto& l : c->side) {
+			if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+			if (l.control) (void)hipFree(l.control);
+			if (l.ev0) (void)hipEventDestroy(l.ev0);
+			if (l.ev1) (void)hipEventDestroy(l.ev1);
+			if (l.done) (void)hipEventDestroy(l.done);
+		}
+		if (c->fork) (void)hipEventDestroy(c->fork);
 		if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
 		if (c->comm) {
 			if (const RcclApi* rccl = RcclApi::get(nullptr)) (void)rccl->CommDestroy(c->comm);
@@ -828,6 +910,7 @@ int32_t rthip_set_option(rthip_ctx* c, const char* name, double value) {
 		else if (k == "acc_lds") t.acc_lds = iv;
 		else if (k == "root_leaf") t.root_leaf = iv;
 		else if (k == "packet") t.packet = iv;
+		else if (k == "overlap") t.overlap = iv;
 		else if (k == "pixel_major") t.pixel_major = iv;
 		else if (k == "stack_mem") t.stack_mem = iv;
 		else if (k == "xchg") t.xchg = iv;
@@ -1150,6 +1233,9 @@ int32_t rthip_render_accumulate_async(rthip_ctx* c, const rthip_render_params* p
 		int32_t rc = validate(c, p);
 		if (rc != RTHIP_OK) return rc;
 		HIP_TRY(c, hipSetDevice(c->device));
+		const bool may_overlap = c->tune.overlap != 0 && c->stream == c->own_stream && p->variant != RTHIP_WAVEFRONT && c->accum != nullptr &&
+		                         c->accum_words == (uint64_t)c->tiles_x * c->tiles_y * kTilePixels * kAccumChannels;
+		if (!may_overlap && (rc = join_lanes(c)) != RTHIP_OK) return rc;
 		// No wait for the previous launch: the control block (work counters, statistics) is cleared and
 		// used in stream order, so launches queue up back to back; statistics are those of the last one.
 		if ((rc = ensure_accum(c)) != RTHIP_OK) return rc;
@@ -1158,9 +1244,9 @@ int32_t rthip_render_accumulate_async(rthip_ctx* c, const rthip_render_params* p
 			if (p->precision == RTHIP_F64) return enqueue_wavefront<double>(c, p, c->accum, nullptr);
 			return enqueue_wavefront<float>(c, p, c->accum, nullptr);
 		}
-		if (p->precision == RTHIP_F64) return enqueue_render<double>(c, p, count, c->accum, nullptr);
-		return enqueue_render<float>(c, p, count, c->accum, nullptr);
-	});
+		if (p->precision == RTHIP_F64) return enqueue_render<double>(c, p, count, c->accum, nullptr, nullptr, false, true, may_overlap);
+		return enqueue_render<float>(c, p, count, c->accum, nullptr, nullptr, false, true, may_overlap);
+	}, false);
 }
 
 int32_t rthip_render_accumulate_noalloc(rthip_ctx* c, const rthip_render_params* p) {

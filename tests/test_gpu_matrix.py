@@ -145,3 +145,36 @@ def test_shares_add_up_on_a_large_scene(rt):
             r.accumulate(count, spp_begin=begin)
         assert np.array_equal(r.read_accum(), whole), opts
         r.close()
+
+
+@pytest.mark.parametrize("scene,cam", [("default", CAM), ("synthetic:5000", CAM5)])
+def test_short_launches_that_overlap_add_up(rt, scene, cam):
+    """A viewer's loop: 1-spp frames queued without waits on the context's own stream, which the library
+    spreads over three streams so that their tails overlap.  The sum is the words of one launch of all the
+    samples (integer adds), a reset or a read-back in between is ordered behind every launch in flight, the
+    statistics are the last launch's, and with the option off the same words come out."""
+    sc = rt.Scene.generate(scene)
+    w, h, frames = 320, 184, 37
+    want = None
+    for opts in ({"overlap": 0}, {}):
+        r = rt.Renderer(sc, rt.Camera(*cam[:5], w, h), seed=12, max_depth=10, options=opts)
+        r.accumulate(frames, spp_begin=0)
+        whole = r.read_accum()
+        if want is None:
+            want = whole
+        assert np.array_equal(whole, want)
+        r.reset_accumulation()
+        for k in range(frames):
+            r.accumulate(1, spp_begin=k, sync=False)
+        assert np.array_equal(r.read_accum(), want), opts          # a read-back right behind the queue of launches
+        assert r.stats()["paths"] == w * h
+        for k in range(5):
+            r.accumulate(1, spp_begin=k, sync=False)
+        r.reset_accumulation()                                     # a clear while launches are in flight comes after them
+        for k in range(frames):
+            r.accumulate(1, spp_begin=k, sync=False)
+            if k == 20:
+                assert r.stats()["rays"] >= w * h                  # a look at the statistics in the middle joins the streams and waits
+        r.synchronize()
+        assert np.array_equal(r.read_accum(), want), opts
+        r.close()
