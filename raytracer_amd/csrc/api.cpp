@@ -355,6 +355,7 @@ struct Plan {
 	int32_t threshold;
 	int waves_per_cu;             // resident waves per CU the launch is planned for
 	bool short_launch;            // fewer paths than 512 per resident wave (a viewer's 1-spp frame)
+	bool overlap_ok;              // small enough for its tail to be worth hiding under the next launch
 	uint32_t xchg_off, xchg_cap;  // exchange queues: where they start in the workgroup's LDS, records per queue
 };
 
@@ -405,8 +406,12 @@ int32_t make_plan(rthip_ctx* c, const rthip_render_params* p, bool count, Plan* 
 	// and tail: small workgroups start sooner and finish closer together, which is worth more there than
 	// resident waves (0.38 ms against 0.46 ms for that frame).
 	plan->short_launch = false;
+	plan->overlap_ok = false;
 	const bool short_launch = in_lds && !wavefront && my_tiles * kTilePixels * (uint64_t)p->spp_count < 512ull * 24 * (uint64_t)c->num_cu;
 	plan->short_launch = short_launch;
+	// (launches up to four times that size still gain from overlapping their tails with the next launch's start:
+	//  2- and 4-spp 1080p frames -23 % and -13 %, a 1-spp 4K frame -16 %; 12-spp frames lose 5 %)
+	plan->overlap_ok = in_lds && !wavefront && my_tiles * kTilePixels * (uint64_t)p->spp_count < 2048ull * 24 * (uint64_t)c->num_cu;
 	// Stacks in global memory: f32 megakernel with the scene in LDS (what the freed LDS is for is decided below).
 	const bool stack_mem = tune.stack_mem > 0 && (in_lds || plan->cfg.quantised) && !f64 && !wavefront && !frugal;  // (the entry point that allocates nothing keeps its stacks in LDS)
 	plan->cfg.stack_mem = stack_mem;
@@ -602,7 +607,7 @@ int32_t enqueue_render(rthip_ctx* c, const rthip_render_params* p, bool count, u
 	hipStream_t stream = c->stream;
 	hipEvent_t ev0 = c->ev0, ev1 = c->ev1;
 	rthip_ctx::Lane* lane = nullptr;
-	if (may_overlap && plan.short_launch && !plan.cfg.stack_mem) {
+	if (may_overlap && plan.overlap_ok && !plan.cfg.stack_mem) {
 		if (c->lane_turn > 0) {
 			lane = &c->side[c->lane_turn - 1];
 			if ((rc = ensure_lane(c, lane)) != RTHIP_OK) return rc;

@@ -9,7 +9,7 @@ import raytracer_amd as rt
 from raytracer_amd import distributed as D
 CAM = ((13.0, 1.5, 3.0), (-13.0, -1.5, -3.0), 20.0, 10.0, 0.6)
 sc = rt.Scene.generate("default")
-for (w, h, spp) in ((1920, 1080, 1), (1920, 1080, 12), (480, 270, 1)):
+for (w, h, spp) in ((1920, 1080, 1), (1920, 1080, 2), (1920, 1080, 4), (1920, 1080, 12), (3840, 2160, 1), (480, 270, 1)):
     ref = None
     for n_ctx in (1, 2, 3):
         buf = D.new_accum_tensor(w, h, "cuda:0")
