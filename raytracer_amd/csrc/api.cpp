@@ -827,6 +827,11 @@ int32_t rthip_create(int32_t device, rthip_ctx** out) {
 		c->num_cu = prop.multiProcessorCount;
 		if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
 		c->stream = c->own_stream;
+		// The side streams of short launches (rthip_ctx::Lane) are made right behind the own stream: a process has few
+		// hardware queues (four by default) that its streams are dealt out to in turn, and streams that share one
+		// do not overlap; made together, the three get three different queues.
+		for (auto& l : c->side)
+			if ((e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
 		if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
 		if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
 		if ((e = hipEventCreateWithFlags(&c->noalloc_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
