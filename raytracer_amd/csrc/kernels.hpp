@@ -516,22 +516,9 @@ template <typename Real> struct Trav {
 	int32_t sp;       // in the stack's own unit, see StackLds / StackMem
 	Real best_t;
 	int32_t best_prim;  // index into prims, -1 = none
-#ifdef RT_SPEC
-	int32_t post;       // a leaf put aside while the lane walks on (0 = none)
-#endif
 };
 RT_FN void trav_begin(Trav<Real>& tv, int32_t stack_bottom) {
 	tv.cur = 0; tv.sp = stack_bottom; tv.best_t = Fp<Real>::max_finite(); tv.best_prim = -1;
-#ifdef RT_SPEC
-	tv.post = 0;
-#endif
-}
-RT_FN bool trav_has_leaf_aside(const Trav<Real>& tv) {
-#ifdef RT_SPEC
-	return tv.post != 0;
-#else
-	return false;
-#endif
 }
 struct Tally { uint32_t box, sphere, cube; };
 // Instrumented builds only: per code region, the lane-iterations executed (sum over active
@@ -580,12 +567,6 @@ template <typename Real, typename Stack, bool kCount>
 __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& r, const Node<Real>* nodes, const Stack& stack, Tally& tally, Regions& rg,
                                            int32_t inner_exit = 0) {
 	const int32_t min_lanes = ((int32_t)__popcll(__ballot(tv.cur >= 0)) * inner_exit + 15) >> 4;  // fewer than inner_exit sixteenths of those that entered
-#ifdef RT_SPEC
-	// A lane that arrives at a leaf while others still descend puts the leaf aside (tv.post) and walks on
-	// from its stack instead of waiting: the leaf is tested in the leaf step that follows, with whatever
-	// the lane reaches next.
-	if (tv.cur < 0 && tv.cur != kDone && tv.post == 0) { tv.post = tv.cur; trav_pop<Real>(tv, stack); }
-#endif
 	while (tv.cur >= 0) {
 		if ((int32_t)__popcll(__ballot(1)) < min_lanes) break;  // the rest wait at leaves: serve them first
 		region_tick<kCount>(rg, kRegInner);
@@ -606,9 +587,6 @@ __device__ __forceinline__ void trav_inner(Trav<Real>& tv, const TravRay<Real>& 
 		} else {
 			trav_pop<Real>(tv, stack);
 		}
-#ifdef RT_SPEC
-		if (tv.cur < 0 && tv.cur != kDone && tv.post == 0) { tv.post = tv.cur; trav_pop<Real>(tv, stack); }
-#endif
 	}
 }
 // The same descent over quantised nodes (f32 trees in global memory): two 16-byte loads per
@@ -683,19 +661,8 @@ __device__ __forceinline__ void leaf_tests(Trav<Real>& tv, const TravRay<Real>& 
 }
 template <typename Real, typename Stack, bool kCount>
 __device__ __forceinline__ void trav_leaf(Trav<Real>& tv, const TravRay<Real>& r, const Prim<Real>* prims, const Gate<Real>* gates, const Stack& stack, Tally& tally, Regions& rg) {
-#ifdef RT_SPEC
-	for (;;) {  // the leaf put aside, then the one the lane stands at
-		const bool at_leaf = tv.cur < 0 && tv.cur != kDone;
-		const int32_t leaf = tv.post != 0 ? tv.post : (at_leaf ? tv.cur : 0);
-		if (leaf == 0) break;
-		leaf_tests<Real, kCount>(tv, r, leaf, prims, gates, tally, rg);
-		if (tv.post != 0) tv.post = 0;
-		else trav_pop<Real>(tv, stack);
-	}
-#else
 	leaf_tests<Real, kCount>(tv, r, tv.cur, prims, gates, tally, rg);
 	trav_pop<Real>(tv, stack);
-#endif
 }
 
 // The 64 camera rays of one batch (an 8x8 tile, one sample) walked through the tree TOGETHER: one
@@ -1635,11 +1602,7 @@ __global__ __launch_bounds__(kThreads, (std::is_same<Real, float>::value && RT_M
 				else trav_inner<Real, Stack, kCount>(tv, ray, nodes, stack, tally, rg, A.inner_exit);
 				phase_end<kCount>(rg, kPhInner, t_ph);
 				t_ph = phase_begin<kCount>();
-#ifdef RT_SPEC
-				if (tv.post != 0 || (tv.cur < 0 && tv.cur != kDone)) trav_leaf<Real, Stack, kCount>(tv, leaf_ray<kQ, Real>(ray), prims, gates, stack, tally, rg);
-#else
 				if (tv.cur < 0 && tv.cur != kDone) trav_leaf<Real, Stack, kCount>(tv, leaf_ray<kQ, Real>(ray), prims, gates, stack, tally, rg);
-#endif
 				phase_end<kCount>(rg, kPhLeaf, t_ph);
 				if (tv.cur == kDone) state = kShade;
 			}
@@ -1686,7 +1649,7 @@ __global__ __launch_bounds__(kProbeBlock) void probe_kernel(ProbeArgs<Real> A) {
 	Regions rg{};
 	while (tv.cur != kDone) {
 		trav_inner<Real, Stack, false>(tv, ray, nodes, stack, tally, rg);
-		if (tv.cur != kDone || trav_has_leaf_aside<Real>(tv)) trav_leaf<Real, Stack, false>(tv, ray, prims, gates, stack, tally, rg);
+		if (tv.cur != kDone) trav_leaf<Real, Stack, false>(tv, ray, prims, gates, stack, tally, rg);
 	}
 	if (tv.best_prim < 0) {
 		A.id[i] = -1; A.t[i] = 0.0; A.front[i] = 0;

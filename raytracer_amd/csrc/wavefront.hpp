@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void wf_extend(WfArgs<Real> A) {
 		if (__ballot(busy) == 0ull) break;
 		if (busy) {
 			trav_inner<Real, Stack, false>(tv, ray, nodes, stack, tally, rg);
-			if (tv.cur != kDone || trav_has_leaf_aside<Real>(tv)) trav_leaf<Real, Stack, false>(tv, ray, prims, gates, stack, tally, rg);
+			if (tv.cur != kDone) trav_leaf<Real, Stack, false>(tv, ray, prims, gates, stack, tally, rg);
 			if (tv.cur == kDone) {
 				A.hit_t[index] = tv.best_t;
 				A.hit_prim[index] = tv.best_prim;
