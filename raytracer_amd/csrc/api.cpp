@@ -1429,6 +1429,7 @@ int32_t rthip_merge_local(rthip_ctx* const* ctxs, int32_t n, int32_t root) {
 			if (k == root) continue;
 			if (!src || !src->has_camera) return fail(dst, RTHIP_ERR_STATE, "a context of the list has no camera");
 			HIP_TRY(dst, hipSetDevice(src->device));
+			if ((rc = join_lanes(src)) != RTHIP_OK) return fail(dst, rc, src->err);   // short launches it spread over its side streams come first
 			if ((rc = ensure_accum(src)) != RTHIP_OK) return fail(dst, rc, src->err);
 			if (src->accum_words != dst->accum_words) return fail(dst, RTHIP_ERR_INVALID, "the contexts render frames of different sizes");
 			if (src->accum == dst->accum) return fail(dst, RTHIP_ERR_INVALID, "two contexts of the list share one accumulation buffer");
